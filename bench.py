@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- RealSR x4 tiled inference on MI355X: BASELINE.json's metric on its config C2.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (rsr_process_device: preproc -> 351 fused convs -> postproc over all
+60 tiles) over one synthetic 1920x1080 RGB frame per GPU, input and output resident in HBM.
+One process per GPU; the only collective is the broadcast of the packed weights (RCCL) at load.
+Weak scaling: every rank upsamples its own frame each step; value = total output Mpix / max-rank time.
+
+Prints ONE JSON line (rank 0).  The CPU oracle is used only for the cpu_baseline leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import realsr_ncnn_vulkan_amd as R  # noqa: E402
+from realsr_ncnn_vulkan_amd import synth  # noqa: E402
+
+W_IN, H_IN, TILE, PREPAD, SCALE = 1920, 1080, 200, 10, 4
+FLOP_PER_PADDED_LR_PX = 35853696  # 2 x 17,926,848 MAC
+PEAK_F16_TFLOPS = 2500.0  # gfx950 dense f16 MFMA peak, MI355X_MICROARCH.md
+
+
+def padded_px(w, h, T, P):
+    n = 0
+    for y0 in range(0, h, T):
+        for x0 in range(0, w, T):
+            n += (min(x0 + T, w) - x0 + 2 * P) * (min(y0 + T, h) - y0 + 2 * P)
+    return n
+
+
+def cpu_baseline(pp, bp):
+    """Oracle (CPU restatement, NOT ncnn) on a bounded sample: one 200x200 image at tile 200 = exactly one
+    padded 220x220 tile of the C2 workload (1.735 TFLOP)."""
+    import oracle
+    net = oracle.OracleNet(pp, bp)
+    img = synth.make_image(1234, 200, 200)
+    net.process(synth.make_image(1, 24, 24), 200)  # warm the thread pool
+    t = time.time()
+    out = net.process(img, 200)
+    dt = time.time() - t
+    return {"value": round(out.shape[0] * out.shape[1] / 1e6 / dt, 5), "unit": "Mpix/s", "cores": oracle.max_threads(),
+            "kind": "port",
+            "sample": "oracle/realsr_oracle.c (CPU restatement of RealSR::process_cpu, not ncnn), one 200x200 "
+                      "image at tile=200 = one padded 220x220 tile of the C2 frame, %.1f s, %.1f GFLOP/s" % (
+                          dt, 220 * 220 * FLOP_PER_PADDED_LR_PX / dt / 1e9)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    d = synth.make_model_dir(os.environ.get("RSR_MODELS", "/tmp/rsr_models"), "models-DF2K", 42) if rank == 0 else None
+    if world > 1:
+        dist.barrier()
+        d = synth.make_model_dir(os.environ.get("RSR_MODELS", "/tmp/rsr_models"), "models-DF2K", 42)
+    pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+
+    # ---- weights: rank 0 parses + packs once, ONE broadcast over xGMI, every rank loads the blob ----
+    if rank == 0:
+        blob = torch.from_numpy(R.model_pack(pp, bp)).to(dev)
+        n = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
+    else:
+        n = torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(n, 0)
+        if rank != 0:
+            blob = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+        dist.broadcast(blob, 0)
+    torch.cuda.synchronize()
+    sr = R.RealSR(local)
+    sr.load_packed(blob.numel(), device_ptr=blob.data_ptr())
+    sr.tilesize, sr.prepadding, sr.scale = TILE, PREPAD, SCALE
+
+    img = synth.make_image(1235 + rank, W_IN, H_IN)  # image seed 1234 + cfg
+    d_in = torch.from_numpy(img).to(dev)
+    d_out = torch.empty((H_IN * SCALE, W_IN * SCALE, 3), dtype=torch.uint8, device=dev)
+
+    def step():
+        sr.process_device(d_in.data_ptr(), W_IN, H_IN, 3, d_out.data_ptr())  # synchronous (own stream + sync)
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        sr.set_profiling(True)
+        sr.get_profile(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = sr.get_profile(reset=True) if not args.no_profile else None
+    sr.set_profiling(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    checksum = int(d_out[::97, ::89].to(torch.int64).sum().item())
+
+    if rank == 0:
+        out_mpix = W_IN * SCALE * H_IN * SCALE / 1e6
+        ppx = padded_px(W_IN, H_IN, TILE, PREPAD)
+        res = {
+            "metric": "output Mpix/s (4x upscale) DF2K tile=200",
+            "value": round(out_mpix * world * args.steps / dt, 3),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2: models-DF2K, 1920x1080 RGB -> 7680x4320, scale=4, tile=200, prepadding=10, "
+                            "60 tiles/frame (2,544,000 padded LR px, 91.21 TFLOP algorithmic), 1 frame per GPU per step",
+                "weights": "synthetic seeded fp16-tagged x4.bin (real blobs absent from the reference checkout)",
+                "io": "uint8 HWC in HBM -> uint8 HWC in HBM (rsr_process_device)",
+                "parallelism": "frames sharded 1/GPU, weights by one RCCL broadcast" if world > 1 else "single GPU",
+                "frame_tflop": round(ppx * FLOP_PER_PADDED_LR_PX / 1e12, 2),
+                "whole_path_tflops": round(ppx * FLOP_PER_PADDED_LR_PX * world * args.steps / dt / 1e12, 1),
+                "checksum": checksum,
+            },
+        }
+        if prof and prof["conv_ms"] > 0:
+            ach = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
+            res["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+                "kernel": "rsr::conv3x3_mfma<NT,UPS,DMA> (all 351 convs x 60 tiles)",
+                "launches": prof["conv_launches"],
+                "avg_launch_us": round(prof["conv_ms"] * 1e3 / max(prof["conv_launches"], 1), 2),
+                "algorithmic_flop_per_launch_avg": round(prof["conv_flops"] / max(prof["conv_launches"], 1)),
+                "conv_ms_per_step": round(prof["conv_ms"] / args.steps, 3),
+                "pre_ms_per_step": round(prof["pre_ms"] / args.steps, 4),
+                "post_ms_per_step": round(prof["post_ms"] / args.steps, 4),
+                "post_GBps": round(prof["post_bytes"] / max(prof["post_ms"], 1e-9) / 1e6, 1),
+                "timing": "hipEvents on the launch stream around every kernel of the timed steps (rank 0)",
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(pp, bp)
+            except Exception as e:  # the oracle is optional here; never fail the GPU number on it
+                res["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(res), flush=True)
+    sr.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/*
+ * realsr_hip.h -- C-ABI of the MI355X-native RealSR x4 tiled-inference engine (librealsr_hip.so).
+ *
+ * This is the drop-in boundary for the reference's `class RealSR`
+ * (/root/reference/src/realsr.h:13-42), the only seam between the CLI/orchestration
+ * (/root/reference/src/main.cpp) and the compute path.  Plain pointers and sizes only; no C++,
+ * ncnn or torch types.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - return 0 = ok, negative = error (RSR_E_*); rsr_last_error() gives a message.  (The reference
+ *     returns 0 unconditionally and its callers ignore the value -- main.cpp:786,325 -- so this is a
+ *     strict superset.)
+ *   - images are HWC uint8, tightly packed, c in {3,4}, RGB(A) order (main.cpp:275-276); the output is
+ *     caller-allocated (w*scale) x (h*scale) x c.  The engine never retains either pointer.
+ *   - one context per GPU (main.cpp:778-791); rsr_process* are thread-safe on a shared context
+ *     (the reference calls process() concurrently from jobs_proc threads, main.cpp:811-828).
+ *   - there is NO CPU fallback: gpuid must name a HIP device; the reference's "-g -1" CPU path
+ *     (RealSR::process_cpu) lives only in oracle/ as the parity checker.
+ */
+#ifndef REALSR_HIP_H
+#define REALSR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSR_OK 0
+#define RSR_E_ARG (-1)      /* bad argument */
+#define RSR_E_IO (-2)       /* cannot open / truncated file */
+#define RSR_E_FORMAT (-3)   /* .param/.bin not parseable */
+#define RSR_E_GRAPH (-4)    /* parsed graph is not the RRDBNet(3,3,64,23,32) x4.param describes */
+#define RSR_E_DEVICE (-5)   /* HIP error / no such device */
+#define RSR_E_STATE (-6)    /* call order (e.g. process before load) */
+#define RSR_E_NOMEM (-7)
+
+typedef struct rsr_ctx rsr_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+
+/* RealSR::RealSR(int gpuid, bool tta_mode, int num_threads)   realsr.h:16, realsr.cpp:13-23.
+ * gpuid: HIP device ordinal (>= 0).  num_threads is accepted for signature parity and ignored
+ * (it only sizes ncnn's CPU thread pool in the reference, realsr.cpp:17). */
+int rsr_create(rsr_ctx** out, int gpuid, int tta_mode, int num_threads);
+
+/* RealSR::~RealSR   realsr.cpp:25-35 */
+void rsr_destroy(rsr_ctx* ctx);
+
+/* RealSR::load(parampath, modelpath)   realsr.h:19-23, realsr.cpp:37-143.
+ * Parses the ncnn text graph and tagged weight stream (fp16-tagged or raw fp32), checks that the
+ * DAG is exactly the x4.param RRDBNet, packs the weights for the MFMA kernels and uploads them. */
+int rsr_load(rsr_ctx* ctx, const char* parampath, const char* modelpath);
+
+/* The public mutable fields `scale`, `tilesize`, `prepadding` assigned after load()
+ * (realsr.h:31-33, main.cpp:788-790).  scale must be 4 (main.cpp:533-537); tilesize >= 32
+ * (main.cpp:539-552; smaller values are accepted for tests, >= 1); prepadding >= 0 (10 for
+ * models-DF2K*, main.cpp:663-667). */
+int rsr_set_params(rsr_ctx* ctx, int scale, int tilesize, int prepadding);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+
+/* RealSR::process(const ncnn::Mat& in, ncnn::Mat& out) const   realsr.h:25, realsr.cpp:145-523.
+ * `in`/`out` are HOST pointers (what ncnn::Mat::data is at main.cpp:275-276).  H2D, all tiles,
+ * D2H; returns when `out` is complete. */
+int rsr_process(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out);
+
+/* Same computation with both images already resident in this context's device memory
+ * (what the reference keeps in VkMat in_gpu/out_gpu, realsr.cpp:211-233, minus the PCIe hops).
+ * `stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous when a stream is
+ * given: the caller synchronises. */
+int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void* d_out, void* stream);
+
+/* ---- weights as one relocatable blob (multi-GPU load path) -------------------------------- */
+/* The reference re-reads x4.bin once per GPU (main.cpp:784-786).  Here rank 0 parses and packs once,
+ * the blob travels by a single RCCL broadcast over xGMI (done by the caller, e.g.
+ * torch.distributed.broadcast with backend nccl), and every rank loads it with rsr_load_packed. */
+
+/* Host-only: parse + validate + pack into `dst` (capacity `cap` bytes).  *need receives the blob
+ * size; call with dst=NULL to query.  No GPU required. */
+int rsr_model_pack(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need);
+
+/* Load a blob produced by rsr_model_pack.  `blob` may be a host pointer (is_device=0) or a device
+ * pointer on this context's GPU (is_device=1). */
+int rsr_load_packed(rsr_ctx* ctx, const void* blob, size_t bytes, int is_device);
+
+/* Host-only model introspection (no GPU): conv count, weight/bias counts and the .bin encoding
+ * (1 = fp16-tagged, 0 = raw fp32, 2 = mixed/table).  Any pointer may be NULL. */
+int rsr_model_info(const char* parampath, const char* modelpath, int* n_layers, int* n_convs,
+                   long long* n_weights, long long* n_biases, int* bin_encoding);
+
+/* ---- the four shader-equivalent kernels, callable alone (bit-exact parity tests) ----------- */
+/* Arguments mirror the shaders' push constants; all pointers are HOST pointers, the call copies
+ * in, runs the HIP kernel, copies out, synchronises.
+ *
+ * rsr_preproc:  realsr_preproc.comp:47-95 / dispatch realsr.cpp:372-415
+ *   band  u8 HWC (w x h x channels) -> top: planar fp16 [3][outh][outw] (cstep = outw*outh),
+ *   alpha: fp16 [alphah][alphaw] un-normalised (only when channels == 4, may be NULL otherwise).
+ * rsr_preproc_tta: realsr_preproc_tta.comp:54-113; top[0..3] are outw x outh, top[4..7] outh x outw. */
+int rsr_preproc(rsr_ctx* ctx, const uint8_t* band, int w, int h, int channels, uint16_t* top, int outw,
+                int outh, int pad_top, int pad_left, int crop_x, int crop_y, uint16_t* alpha, int alphaw,
+                int alphah);
+int rsr_preproc_tta(rsr_ctx* ctx, const uint8_t* band, int w, int h, int channels, uint16_t* const top[8],
+                    int outw, int outh, int pad_top, int pad_left, int crop_x, int crop_y);
+
+/* rsr_postproc: realsr_postproc.comp:47-89 / dispatch realsr.cpp:444-472
+ *   bottom planar fp16 [3][h][w] -> top u8 HWC band (outw x outh x channels), written in place
+ *   for gx < gx_max at column offset offset_x (the band is copied in first, so untouched pixels
+ *   keep their value).  alpha (channels==4): fp16 [alphah][alphaw], 0..255 units.
+ * rsr_postproc_tta: realsr_postproc_tta.comp:54-110. */
+int rsr_postproc(rsr_ctx* ctx, const uint16_t* bottom, int w, int h, const uint16_t* alpha, int alphaw,
+                 int alphah, uint8_t* top, int outw, int outh, int offset_x, int gx_max, int crop_x, int crop_y,
+                 int channels);
+int rsr_postproc_tta(rsr_ctx* ctx, const uint16_t* const bottom[8], int w, int h, uint8_t* top, int outw,
+                     int outh, int offset_x, int gx_max, int crop_x, int crop_y, int channels);
+
+/* ---- network on one tile (layer-level parity; replaces ncnn::Extractor input/extract,
+ *      realsr.cpp:420-428) -------------------------------------------------------------------- */
+/* in: planar fp16 [3][h][w] in [0,1]; out: planar fp16 [3][4h][4w].  Host pointers. */
+int rsr_net_forward(rsr_ctx* ctx, const uint16_t* in, int w, int h, uint16_t* out);
+
+/* One 3x3/s1/p1 convolution through the MFMA kernel with caller-supplied weights (layer-level parity;
+ * the arithmetic ncnn::Convolution [+ Interp nearest x2 in front when upsample2x] performs for each
+ * Convolution line of x4.param).  in: planar fp16 [cin][h][w]; weight: fp32 OIHW [cout][cin][3][3]
+ * (rounded to fp16 by the packer); bias fp32 [cout]; cout <= 64; out: planar fp16 [cout][H][W],
+ * H,W = h,w (or 2h,2w).  Host pointers. */
+int rsr_conv3x3(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, int upsample2x, const float* weight,
+                const float* bias, int cout, int lrelu, uint16_t* out);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+typedef struct rsr_profile
+{
+    double conv_ms;        /* summed HIP-event time of the conv3x3 MFMA kernel launches */
+    double conv_flops;     /* algorithmic FLOPs of those launches: 2*9*Cin*Cout*H*W per tile (true Cin/Cout) */
+    long long conv_launches;
+    double pre_ms, post_ms; /* preproc / postproc kernels */
+    double pre_bytes, post_bytes;
+    double total_ms;       /* first launch -> last launch of the profiled rsr_process* calls */
+    long long tiles;       /* network tile evaluations (x8 under TTA) */
+    long long calls;
+} rsr_profile;
+
+/* enable=1: every kernel launch is bracketed by hipEvents on the launch stream; accumulate until
+ * rsr_get_profile(reset=1).  The events add ~1 us per launch. */
+int rsr_set_profiling(rsr_ctx* ctx, int enable);
+int rsr_get_profile(rsr_ctx* ctx, rsr_profile* out, int reset);
+
+/* Engine knobs (optional).  key/value: "max_workspace_mb" (tile batch memory budget),
+ * "trunk_fp32" (1: residual trunk kept in fp32 [default], 0: fp16 storage like the reference's
+ * Vulkan path). */
+int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
+
+const char* rsr_last_error(const rsr_ctx* ctx); /* ctx may be NULL: last global (create/pack) error */
+const char* rsr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REALSR_HIP_H */

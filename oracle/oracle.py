@@ -60,6 +60,9 @@ def lib():
                                        C.c_int, C.c_int]
         L.orc_max_threads.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
+        # The oracle's parallel regions are small (one per layer): on many-core hosts (the GPU box has
+        # 256 hardware threads) an unbounded OpenMP team is ~1000x slower than 16 threads.
+        L.orc_set_threads(max(1, min(16, os.cpu_count() or 1)))
         _lib = L
     return _lib
 

@@ -153,8 +153,7 @@ static int blob_index(orc_net* n, const char* name)
     for (int i = 0; i < n->nblob_names; i++)
         if (strcmp(n->blob_names[i], name) == 0) return i;
     if (n->nblob_names >= n->nblobs) return -1;
-    strncpy(n->blob_names[n->nblob_names], name, 63);
-    n->blob_names[n->nblob_names][63] = 0;
+    snprintf(n->blob_names[n->nblob_names], 64, "%s", name);
     return n->nblob_names++;
 }
 
@@ -1059,6 +1058,9 @@ ORC_API void orc_preproc(const uint8_t* bottom, int w, int h, int channels, uint
                 y = abs(y);
                 x = (w - 1) - abs(x - (w - 1));
                 y = (h - 1) - abs(y - (h - 1));
+                /* halo larger than the band (tiny images): the shader would index out of bounds; clamp */
+                x = x < 0 ? 0 : x;
+                y = y < 0 ? 0 : y;
                 int v_offset = y * w + x;
                 float v;
                 if (bgr == 1 && gz != 3) v = (float)bottom[v_offset * channels + 2 - gz]; /* :69-72 */
@@ -1126,6 +1128,9 @@ ORC_API void orc_preproc_tta(const uint8_t* bottom, int w, int h, int channels, 
                 y = abs(y);
                 x = (w - 1) - abs(x - (w - 1));
                 y = (h - 1) - abs(y - (h - 1));
+                /* halo larger than the band (tiny images): the shader would index out of bounds; clamp */
+                x = x < 0 ? 0 : x;
+                y = y < 0 ? 0 : y;
                 int v_offset = y * w + x;
                 float v;
                 if (bgr == 1 && gz != 3) v = (float)bottom[v_offset * channels + 2 - gz];

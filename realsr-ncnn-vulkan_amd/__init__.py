@@ -1,0 +1,258 @@
+"""realsr-ncnn-vulkan_amd -- MI355X-native RealSR x4 tiled inference.
+
+The product is the C-ABI shared library `lib/librealsr_hip.so` (include/realsr_hip.h), built from
+`csrc/` with hipcc for gfx950.  This module is only a thin ctypes binding used by the tests, the
+bench and `__graft_entry__`; the reference-shaped C++ host class lives in csrc/realsr.h.
+
+There is no CPU fallback: importing works anywhere (the library links against libamdhip64 only), but
+creating a `RealSR` without a gfx950 device raises.  The directory name carries a hyphen (it is the
+reference's name + `_amd`); import it through the repo-root shim `realsr_ncnn_vulkan_amd.py`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librealsr_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+EXPORTS = [
+    "rsr_create", "rsr_destroy", "rsr_load", "rsr_set_params", "rsr_process", "rsr_process_device",
+    "rsr_model_pack", "rsr_load_packed", "rsr_model_info", "rsr_preproc", "rsr_preproc_tta", "rsr_postproc",
+    "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile",
+    "rsr_set_option", "rsr_last_error", "rsr_version",
+]
+
+RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class Profile(C.Structure):
+    _fields_ = [("conv_ms", C.c_double), ("conv_flops", C.c_double), ("conv_launches", C.c_longlong),
+                ("pre_ms", C.c_double), ("post_ms", C.c_double), ("pre_bytes", C.c_double),
+                ("post_bytes", C.c_double), ("total_ms", C.c_double), ("tiles", C.c_longlong),
+                ("calls", C.c_longlong)]
+
+
+class RealSRError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rsr error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/ into lib/librealsr_hip.so with hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        cmd.append("-B")
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library.  Fails loudly if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or make -C realsr-ncnn-vulkan_amd/csrc)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip, cp = C.c_void_p, C.c_int, C.c_char_p
+    L.rsr_create.argtypes = [C.POINTER(vp), ip, ip, ip]
+    L.rsr_destroy.argtypes = [vp]
+    L.rsr_destroy.restype = None
+    L.rsr_load.argtypes = [vp, cp, cp]
+    L.rsr_set_params.argtypes = [vp, ip, ip, ip]
+    L.rsr_process.argtypes = [vp, vp, ip, ip, ip, vp]
+    L.rsr_process_device.argtypes = [vp, vp, ip, ip, ip, vp, vp]
+    L.rsr_model_pack.argtypes = [cp, cp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rsr_load_packed.argtypes = [vp, vp, C.c_size_t, ip]
+    L.rsr_model_info.argtypes = [cp, cp, C.POINTER(ip), C.POINTER(ip), C.POINTER(C.c_longlong),
+                                 C.POINTER(C.c_longlong), C.POINTER(ip)]
+    L.rsr_preproc.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip, ip, ip, ip, ip, vp, ip, ip]
+    L.rsr_preproc_tta.argtypes = [vp, vp, ip, ip, ip, C.POINTER(vp), ip, ip, ip, ip, ip, ip]
+    L.rsr_postproc.argtypes = [vp, vp, ip, ip, vp, ip, ip, vp, ip, ip, ip, ip, ip, ip, ip]
+    L.rsr_postproc_tta.argtypes = [vp, C.POINTER(vp), ip, ip, vp, ip, ip, ip, ip, ip, ip, ip]
+    L.rsr_net_forward.argtypes = [vp, vp, ip, ip, vp]
+    L.rsr_conv3x3.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp]
+    L.rsr_set_profiling.argtypes = [vp, ip]
+    L.rsr_get_profile.argtypes = [vp, C.POINTER(Profile), ip]
+    L.rsr_set_option.argtypes = [vp, cp, C.c_longlong]
+    L.rsr_last_error.argtypes = [vp]
+    L.rsr_last_error.restype = cp
+    L.rsr_version.restype = cp
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def model_info(param_path, bin_path):
+    """Host-only parse + graph validation (no GPU).  Returns dict."""
+    L = lib()
+    nl, nc, enc = C.c_int(), C.c_int(), C.c_int()
+    nw, nb = C.c_longlong(), C.c_longlong()
+    rc = L.rsr_model_info(str(param_path).encode(), str(bin_path).encode(), nl, nc, nw, nb, enc)
+    if rc != 0:
+        raise RealSRError(rc, L.rsr_last_error(None).decode())
+    return dict(n_layers=nl.value, n_convs=nc.value, n_weights=nw.value, n_biases=nb.value, bin_encoding=enc.value)
+
+
+def model_pack(param_path, bin_path):
+    """Host-only: parse, validate and pack the model into one relocatable blob (np.uint8 array)."""
+    L = lib()
+    need = C.c_size_t()
+    rc = L.rsr_model_pack(str(param_path).encode(), str(bin_path).encode(), None, 0, need)
+    if rc != 0:
+        raise RealSRError(rc, L.rsr_last_error(None).decode())
+    buf = np.zeros(need.value, dtype=np.uint8)
+    rc = L.rsr_model_pack(str(param_path).encode(), str(bin_path).encode(), _p(buf), buf.size, need)
+    if rc != 0:
+        raise RealSRError(rc, L.rsr_last_error(None).decode())
+    return buf
+
+
+class RealSR:
+    """Python mirror of the reference's `class RealSR` (realsr.h:13-42) over the C-ABI.
+
+    RealSR(gpuid, tta_mode=False, num_threads=1); load(parampath, modelpath); fields scale / tilesize /
+    prepadding; process(in HWC uint8) -> out HWC uint8.
+    """
+
+    def __init__(self, gpuid, tta_mode=False, num_threads=1):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.rsr_create(C.byref(h), int(gpuid), int(bool(tta_mode)), int(num_threads))
+        if rc != 0:
+            raise RealSRError(rc, self._L.rsr_last_error(None).decode())
+        self._h = h
+        self.scale, self.tilesize, self.prepadding = 4, 200, 10
+        self.tta_mode = bool(tta_mode)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rsr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RealSRError(rc, self._L.rsr_last_error(self._h).decode())
+
+    def load(self, parampath, modelpath):
+        self._ck(self._L.rsr_load(self._h, str(parampath).encode(), str(modelpath).encode()))
+        return 0
+
+    def load_packed(self, blob, device_ptr=None):
+        """blob: np.uint8 array (host), or pass device_ptr (int) + blob = nbytes."""
+        if device_ptr is not None:
+            self._ck(self._L.rsr_load_packed(self._h, C.c_void_p(int(device_ptr)), int(blob), 1))
+        else:
+            blob = np.ascontiguousarray(blob, dtype=np.uint8)
+            self._ck(self._L.rsr_load_packed(self._h, _p(blob), blob.size, 0))
+
+    def _push_params(self):
+        self._ck(self._L.rsr_set_params(self._h, int(self.scale), int(self.tilesize), int(self.prepadding)))
+
+    def set_option(self, key, value):
+        self._ck(self._L.rsr_set_option(self._h, key.encode(), int(value)))
+
+    def process(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w, c = img.shape
+        self._push_params()
+        out = np.empty((h * self.scale, w * self.scale, c), dtype=np.uint8)
+        self._ck(self._L.rsr_process(self._h, _p(img), w, h, c, _p(out)))
+        return out
+
+    def process_device(self, d_in, w, h, c, d_out, stream=None):
+        """d_in/d_out: integer device pointers (e.g. torch tensor .data_ptr())."""
+        self._push_params()
+        self._ck(self._L.rsr_process_device(self._h, C.c_void_p(int(d_in)), w, h, c, C.c_void_p(int(d_out)),
+                                            C.c_void_p(int(stream)) if stream else None))
+
+    def net_forward(self, x):
+        """x: float16 planar (3,h,w) -> float16 (3,4h,4w)."""
+        x = np.ascontiguousarray(x, dtype=np.float16)
+        _, h, w = x.shape
+        out = np.empty((3, 4 * h, 4 * w), dtype=np.float16)
+        self._ck(self._L.rsr_net_forward(self._h, _p(x), w, h, _p(out)))
+        return out
+
+    def conv3x3(self, x, weight, bias, lrelu=False, upsample2x=False):
+        x = np.ascontiguousarray(x, dtype=np.float16)
+        weight = np.ascontiguousarray(weight, dtype=np.float32)
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+        cin, h, w = x.shape
+        cout = weight.shape[0]
+        s = 2 if upsample2x else 1
+        out = np.empty((cout, h * s, w * s), dtype=np.float16)
+        self._ck(self._L.rsr_conv3x3(self._h, _p(x), cin, h, w, int(upsample2x), _p(weight), _p(bias), cout, int(lrelu), _p(out)))
+        return out
+
+    def preproc(self, band, outw, outh, pad_top, pad_left, crop_x, crop_y, alphaw=0, alphah=0):
+        band = np.ascontiguousarray(band, dtype=np.uint8)
+        h, w, c = band.shape
+        top = np.zeros((3, outh, outw), dtype=np.float16)
+        alpha = np.zeros((alphah, alphaw), dtype=np.float16) if c == 4 else None
+        self._ck(self._L.rsr_preproc(self._h, _p(band), w, h, c, _p(top), outw, outh, pad_top, pad_left, crop_x, crop_y,
+                                     _p(alpha), alphaw, alphah))
+        return (top, alpha) if c == 4 else top
+
+    def preproc_tta(self, band, outw, outh, pad_top, pad_left, crop_x, crop_y):
+        band = np.ascontiguousarray(band, dtype=np.uint8)
+        h, w, c = band.shape
+        tops = [np.zeros((3, outh, outw) if k < 4 else (3, outw, outh), dtype=np.float16) for k in range(8)]
+        arr = (C.c_void_p * 8)(*[t.ctypes.data for t in tops])
+        self._ck(self._L.rsr_preproc_tta(self._h, _p(band), w, h, c, arr, outw, outh, pad_top, pad_left, crop_x, crop_y))
+        return tops
+
+    def postproc(self, bottom, out_band, offset_x, gx_max, crop_x, crop_y, alpha=None):
+        bottom = np.ascontiguousarray(bottom, dtype=np.float16)
+        _, h, w = bottom.shape
+        outh, outw, c = out_band.shape
+        assert out_band.flags.c_contiguous and out_band.dtype == np.uint8
+        if alpha is not None:
+            alpha = np.ascontiguousarray(alpha, dtype=np.float16)
+        aw = alpha.shape[1] if alpha is not None else 0
+        ah = alpha.shape[0] if alpha is not None else 0
+        self._ck(self._L.rsr_postproc(self._h, _p(bottom), w, h, _p(alpha), aw, ah, _p(out_band), outw, outh, offset_x,
+                                      gx_max, crop_x, crop_y, c))
+        return out_band
+
+    def postproc_tta(self, bottoms, out_band, offset_x, gx_max, crop_x, crop_y):
+        bottoms = [np.ascontiguousarray(b, dtype=np.float16) for b in bottoms]
+        _, h, w = bottoms[0].shape
+        outh, outw, c = out_band.shape
+        arr = (C.c_void_p * 8)(*[b.ctypes.data for b in bottoms])
+        self._ck(self._L.rsr_postproc_tta(self._h, arr, w, h, _p(out_band), outw, outh, offset_x, gx_max, crop_x, crop_y, c))
+        return out_band
+
+    def set_profiling(self, on):
+        self._ck(self._L.rsr_set_profiling(self._h, int(bool(on))))
+
+    def get_profile(self, reset=True):
+        p = Profile()
+        self._ck(self._L.rsr_get_profile(self._h, C.byref(p), int(bool(reset))))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+# ---- tile sharding for multi-GPU runs: pure host logic, shared by bench + tests ----
+def shard_frames(n_frames, world_size, rank):
+    """Frames dealt round-robin to ranks (the reference's work-stealing queue, main.cpp:811-828,
+    made deterministic).  Returns the list of frame indices this rank processes."""
+    return list(range(rank, n_frames, world_size))

@@ -1,0 +1,306 @@
+// capi.cpp -- extern "C" entry points declared in include/realsr_hip.h.
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+using namespace rsr;
+
+struct rsr_ctx
+{
+    Engine e;
+};
+
+static thread_local std::string g_err;
+
+#define CK(expr)                                                          \
+    do                                                                    \
+    {                                                                     \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess)                                             \
+        {                                                                 \
+            rc = ctx->e.fail(RSR_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+            goto done;                                                    \
+        }                                                                 \
+    } while (0)
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* rsr_version(void) { return "realsr-hip 0.1 (gfx950)"; }
+
+const char* rsr_last_error(const rsr_ctx* ctx) { return ctx ? ctx->e.err.c_str() : g_err.c_str(); }
+
+int rsr_create(rsr_ctx** out, int gpuid, int tta_mode, int num_threads)
+{
+    (void)num_threads;
+    if (!out)
+    {
+        g_err = "null out pointer";
+        return RSR_E_ARG;
+    }
+    *out = nullptr;
+    rsr_ctx* c = new (std::nothrow) rsr_ctx;
+    if (!c)
+    {
+        g_err = "out of memory";
+        return RSR_E_NOMEM;
+    }
+    const int rc = c->e.init(gpuid, tta_mode);
+    if (rc != RSR_OK)
+    {
+        g_err = c->e.err;
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return RSR_OK;
+}
+
+void rsr_destroy(rsr_ctx* ctx) { delete ctx; }
+
+int rsr_load(rsr_ctx* ctx, const char* parampath, const char* modelpath)
+{
+    if (!ctx) return RSR_E_ARG;
+    return ctx->e.load_files(parampath, modelpath);
+}
+
+int rsr_set_params(rsr_ctx* ctx, int scale, int tilesize, int prepadding)
+{
+    if (!ctx) return RSR_E_ARG;
+    if (scale != 4) return ctx->e.fail(RSR_E_ARG, "scale must be 4 (main.cpp:533-537)");
+    if (tilesize < 1) return ctx->e.fail(RSR_E_ARG, "tilesize must be >= 1");
+    if (prepadding < 0 || prepadding > 64) return ctx->e.fail(RSR_E_ARG, "prepadding out of range");
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    ctx->e.scale = scale;
+    ctx->e.tilesize = tilesize;
+    ctx->e.prepadding = prepadding;
+    return RSR_OK;
+}
+
+int rsr_process(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out)
+{
+    if (!ctx) return RSR_E_ARG;
+    return ctx->e.process_host(in, w, h, c, out);
+}
+
+int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void* d_out, void* stream)
+{
+    if (!ctx) return RSR_E_ARG;
+    return ctx->e.process_device(d_in, w, h, c, d_out, static_cast<hipStream_t>(stream), stream == nullptr);
+}
+
+int rsr_model_pack(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need)
+{
+    if (!parampath || !modelpath)
+    {
+        g_err = "null path";
+        return RSR_E_ARG;
+    }
+    Model m;
+    int rc = load_model(parampath, modelpath, m, g_err);
+    if (rc != RSR_OK) return rc;
+    const size_t n = packed_size(m);
+    if (need) *need = n;
+    if (!dst) return RSR_OK;
+    return pack_model(m, dst, cap, g_err);
+}
+
+int rsr_load_packed(rsr_ctx* ctx, const void* blob, size_t bytes, int is_device)
+{
+    if (!ctx || !blob) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    return is_device ? ctx->e.load_blob_device(blob, bytes) : ctx->e.load_blob_host(blob, bytes);
+}
+
+int rsr_model_info(const char* parampath, const char* modelpath, int* n_layers, int* n_convs, long long* n_weights,
+                   long long* n_biases, int* bin_encoding)
+{
+    if (!parampath || !modelpath)
+    {
+        g_err = "null path";
+        return RSR_E_ARG;
+    }
+    Model m;
+    const int rc = load_model(parampath, modelpath, m, g_err);
+    if (rc != RSR_OK) return rc;
+    if (n_layers) *n_layers = m.n_layers;
+    if (n_convs) *n_convs = int(m.convs.size());
+    if (n_weights) *n_weights = m.n_weights;
+    if (n_biases) *n_biases = m.n_biases;
+    if (bin_encoding) *bin_encoding = m.bin_encoding;
+    return RSR_OK;
+}
+
+// ---- shader-equivalent kernels, host pointers in/out --------------------------------------------
+static int preproc_common(rsr_ctx* ctx, const uint8_t* band, int w, int h, int channels, uint16_t* const top[8], int ntop,
+                          int outw, int outh, int pad_top, int pad_left, int crop_x, int crop_y, uint16_t* alpha, int alphaw,
+                          int alphah)
+{
+    if (!ctx || !band || !top || w < 1 || h < 1 || (channels != 3 && channels != 4) || outw < 1 || outh < 1) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    int rc = RSR_OK;
+    const size_t nin = size_t(w) * h * channels, ntile = size_t(outw) * outh * 3 * 2;
+    const size_t nalpha = (channels == 4 && alpha) ? size_t(alphaw) * alphah * 2 : 0;
+    uint8_t* d_in = nullptr;
+    uint16_t* d_top[8] = {nullptr};
+    uint16_t* d_alpha = nullptr;
+    hipStream_t st = ctx->e.stream;
+    CK(hipSetDevice(ctx->e.device));
+    CK(hipMalloc(&d_in, nin));
+    CK(hipMemcpy(d_in, band, nin, hipMemcpyHostToDevice));
+    for (int i = 0; i < ntop; i++)
+    {
+        CK(hipMalloc(&d_top[i], ntile));
+        CK(hipMemset(d_top[i], 0, ntile));
+    }
+    if (nalpha)
+    {
+        CK(hipMalloc(&d_alpha, nalpha));
+        CK(hipMemset(d_alpha, 0, nalpha));
+    }
+    launch_preproc_shader(d_in, w, h, channels, d_top, ntop, outw, outh, outw * outh, pad_top, pad_left, crop_x, crop_y, d_alpha,
+                          alphaw, alphah, 0, st);
+    CK(hipStreamSynchronize(st));
+    CK(hipGetLastError());
+    for (int i = 0; i < ntop; i++) CK(hipMemcpy(top[i], d_top[i], ntile, hipMemcpyDeviceToHost));
+    if (nalpha) CK(hipMemcpy(alpha, d_alpha, nalpha, hipMemcpyDeviceToHost));
+done:
+    if (d_in) (void)hipFree(d_in);
+    for (int i = 0; i < 8; i++)
+        if (d_top[i]) (void)hipFree(d_top[i]);
+    if (d_alpha) (void)hipFree(d_alpha);
+    return rc;
+}
+
+int rsr_preproc(rsr_ctx* ctx, const uint8_t* band, int w, int h, int channels, uint16_t* top, int outw, int outh, int pad_top,
+                int pad_left, int crop_x, int crop_y, uint16_t* alpha, int alphaw, int alphah)
+{
+    uint16_t* tops[8] = {top, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!top) return RSR_E_ARG;
+    return preproc_common(ctx, band, w, h, channels, tops, 1, outw, outh, pad_top, pad_left, crop_x, crop_y, alpha, alphaw, alphah);
+}
+
+int rsr_preproc_tta(rsr_ctx* ctx, const uint8_t* band, int w, int h, int channels, uint16_t* const top[8], int outw, int outh,
+                    int pad_top, int pad_left, int crop_x, int crop_y)
+{
+    if (!top) return RSR_E_ARG;
+    for (int i = 0; i < 8; i++)
+        if (!top[i]) return RSR_E_ARG;
+    return preproc_common(ctx, band, w, h, channels, top, 8, outw, outh, pad_top, pad_left, crop_x, crop_y, nullptr, 0, 0);
+}
+
+static int postproc_common(rsr_ctx* ctx, const uint16_t* const bottom[8], int nb, int w, int h, const uint16_t* alpha, int alphaw,
+                           int alphah, uint8_t* top, int outw, int outh, int offset_x, int gx_max, int crop_x, int crop_y,
+                           int channels)
+{
+    if (!ctx || !bottom || !top || w < 1 || h < 1 || (channels != 3 && channels != 4) || outw < 1 || outh < 1 || gx_max < 0)
+        return RSR_E_ARG;
+    if (channels == 4 && !alpha) return RSR_E_ARG;
+    if (gx_max == 0) return RSR_OK;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    int rc = RSR_OK;
+    const size_t ntile = size_t(w) * h * 3 * 2, nout = size_t(outw) * outh * channels;
+    const size_t nalpha = channels == 4 ? size_t(alphaw) * alphah * 2 : 0;
+    uint16_t* d_b[8] = {nullptr};
+    uint16_t* d_alpha = nullptr;
+    uint8_t* d_top = nullptr;
+    hipStream_t st = ctx->e.stream;
+    CK(hipSetDevice(ctx->e.device));
+    for (int i = 0; i < nb; i++)
+    {
+        CK(hipMalloc(&d_b[i], ntile));
+        CK(hipMemcpy(d_b[i], bottom[i], ntile, hipMemcpyHostToDevice));
+    }
+    if (nalpha)
+    {
+        CK(hipMalloc(&d_alpha, nalpha));
+        CK(hipMemcpy(d_alpha, alpha, nalpha, hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&d_top, nout));
+    CK(hipMemcpy(d_top, top, nout, hipMemcpyHostToDevice));
+    launch_postproc_shader(d_b, nb, w, h, w * h, d_alpha, alphaw, alphah, d_top, outw, outh, offset_x, gx_max, crop_x, crop_y,
+                           channels, 0, st);
+    CK(hipStreamSynchronize(st));
+    CK(hipGetLastError());
+    CK(hipMemcpy(top, d_top, nout, hipMemcpyDeviceToHost));
+done:
+    for (int i = 0; i < 8; i++)
+        if (d_b[i]) (void)hipFree(d_b[i]);
+    if (d_alpha) (void)hipFree(d_alpha);
+    if (d_top) (void)hipFree(d_top);
+    return rc;
+}
+
+int rsr_postproc(rsr_ctx* ctx, const uint16_t* bottom, int w, int h, const uint16_t* alpha, int alphaw, int alphah, uint8_t* top,
+                 int outw, int outh, int offset_x, int gx_max, int crop_x, int crop_y, int channels)
+{
+    const uint16_t* b[8] = {bottom, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!bottom) return RSR_E_ARG;
+    return postproc_common(ctx, b, 1, w, h, alpha, alphaw, alphah, top, outw, outh, offset_x, gx_max, crop_x, crop_y, channels);
+}
+
+int rsr_postproc_tta(rsr_ctx* ctx, const uint16_t* const bottom[8], int w, int h, uint8_t* top, int outw, int outh, int offset_x,
+                     int gx_max, int crop_x, int crop_y, int channels)
+{
+    if (!bottom) return RSR_E_ARG;
+    for (int i = 0; i < 8; i++)
+        if (!bottom[i]) return RSR_E_ARG;
+    if (channels != 3) return RSR_E_ARG; // alpha goes through rsr_postproc's path
+    return postproc_common(ctx, bottom, 8, w, h, nullptr, 0, 0, top, outw, outh, offset_x, gx_max, crop_x, crop_y, channels);
+}
+
+int rsr_net_forward(rsr_ctx* ctx, const uint16_t* in, int w, int h, uint16_t* out)
+{
+    if (!ctx) return RSR_E_ARG;
+    return ctx->e.net_forward(in, w, h, out);
+}
+
+int rsr_conv3x3(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, int upsample2x, const float* weight, const float* bias,
+                int cout, int lrelu, uint16_t* out)
+{
+    if (!ctx) return RSR_E_ARG;
+    return ctx->e.conv_test(in, cin, h, w, upsample2x, weight, bias, cout, lrelu, out);
+}
+
+int rsr_set_profiling(rsr_ctx* ctx, int enable)
+{
+    if (!ctx) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    ctx->e.profiling = enable != 0;
+    return RSR_OK;
+}
+
+int rsr_get_profile(rsr_ctx* ctx, rsr_profile* out, int reset)
+{
+    if (!ctx || !out) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    *out = ctx->e.prof;
+    if (reset) std::memset(&ctx->e.prof, 0, sizeof(rsr_profile));
+    return RSR_OK;
+}
+
+int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
+{
+    if (!ctx || !key) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    const std::string k(key);
+    if (k == "max_workspace_mb")
+    {
+        if (value < 1) return ctx->e.fail(RSR_E_ARG, "max_workspace_mb must be >= 1");
+        ctx->e.max_workspace_mb = value;
+        ctx->e.free_plan();
+    }
+    else if (k == "trunk_fp32")
+        ctx->e.trunk_fp32 = value != 0;
+    else if (k == "use_dma")
+        ctx->e.use_dma = value != 0;
+    else
+        return ctx->e.fail(RSR_E_ARG, "unknown option " + k);
+    return RSR_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,124 @@
+// kernels.h -- launch interface of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace rsr {
+
+// ---- activation storage ("planes") -----------------------------------------------------------
+// Every feature tensor lives in HBM as a set of 32-channel planes: plane = [H][W][32] fp16
+// (64 B per pixel, pixels row-major, no border).  A 64-channel tensor = 2 planes, the 192-channel
+// dense-block working set = 6 planes.  Tiles of one batch occupy "slots" at a fixed stride.
+// fp32 residual trunk: [H][W][32] fp32 planes (128 B per pixel).
+//
+// Work decomposition of the conv kernel: one workgroup (256 threads = 4 waves) computes a
+// 16-row x 32-column block of output pixels for all output channels; work items (slot, y0, x0)
+// come from a device table.
+
+constexpr int kBlkH = 16, kBlkW = 32;          // output block of one workgroup
+constexpr int kPatchH = kBlkH + 2, kPatchW = kBlkW + 2;
+constexpr int kPatchPx = kPatchH * kPatchW;     // 612
+constexpr int kPatchBytes = kPatchPx * 64;      // 39168
+constexpr int kPatchLds = 40960;                // LDS bytes reserved for the patch (10 x 256 x 16: whole DMA passes)
+
+struct WorkItem
+{
+    int slot, y0, x0, pad;
+};
+
+struct TileDim
+{
+    int h, w; // LR dims of the (padded) tile living in this slot
+};
+
+struct PlaneSrc
+{
+    const void* base;     // plane 0 of slot 0
+    long long slot_stride;  // bytes between slots
+    long long plane_stride; // bytes between planes
+};
+
+struct ConvArgs
+{
+    // input planes: the first n0 from src0, then n1 from src1 (dense-block x planes + x1..x4 planes)
+    PlaneSrc src0, src1;
+    int n0, n1;
+    int lvl_in;  // input resolution = LR << lvl_in
+    int lvl_out; // output resolution = LR << lvl_out (lvl_out == lvl_in + 1 for the nearest-x2 fused convs)
+    // weights: packed LDS images, one per 32-cin chunk; bias fp32 [NT*32]
+    const void* wpk;
+    const float* bias;
+    int lrelu; // LeakyReLU(0.2) on (acc + bias)
+    // residual stages: v = v*s + r  (r fp32 plane or fp16 plane)
+    PlaneSrc res1, res2;
+    int res1_kind, res2_kind; // 0 none, 1 fp16 planes, 2 fp32 planes
+    float s1, s2;
+    // outputs (any may be null)
+    PlaneSrc out16;  // fp16 planes (NT planes)
+    PlaneSrc out32a; // fp32 planes
+    PlaneSrc out32b;
+    // conv_last: planar fp16 [3][H][W] per slot
+    void* out_planar3;
+    long long planar3_slot_stride; // bytes
+    // work
+    const WorkItem* items;
+    int nitems;
+    const TileDim* dims;
+    const void* zeros; // >= 16 zero bytes in device memory (LDS-DMA source for out-of-image pixels)
+};
+
+void launch_conv(const ConvArgs& a, int nt, bool dma, hipStream_t st);
+
+// ---- pre / post ------------------------------------------------------------------------------
+struct BaseTile
+{
+    int x_org, y_org; // image coords of padded-tile pixel (0,0)  (= xi*T - P, yi*T - P)
+    int tw, th;       // padded tile size
+    int slot0;        // first slot (TTA: 8 consecutive slots)
+    int out_x, out_y; // top-left of this tile's output rectangle in the x4 image
+    int out_w, out_h; // size of that rectangle (tile_w_nopad*4, tile_h_nopad*4)
+};
+
+struct PreArgs
+{
+    const uint8_t* img; // HWC u8
+    int w, h, c;
+    const BaseTile* tiles;
+    int ntiles;
+    int tta;
+    void* in_plane; // fp16 plane [th][tw][32] per slot, channels 0..2 = RGB/255, rest 0
+    long long slot_stride;
+    int bgr;
+};
+void launch_preproc_tiles(const PreArgs& a, int max_tw, int max_th, hipStream_t st);
+
+struct PostArgs
+{
+    const void* planar3; // fp16 [3][4th][4tw] per slot
+    long long slot_stride;
+    const BaseTile* tiles;
+    int ntiles;
+    int tta;
+    int crop;   // prepadding*scale
+    uint8_t* out; // HWC u8 (4w x 4h x c)
+    int out_w, out_h, c;
+    const uint8_t* in_img; // for alpha (c==4): source image (w x h x 4)
+    int in_w, in_h;
+    int tilesize;
+    int bgr;
+};
+void launch_postproc_tiles(const PostArgs& a, int max_ow, int max_oh, hipStream_t st);
+
+// shader-shaped standalone kernels (parity tests): device pointers
+void launch_preproc_shader(const uint8_t* bottom, int w, int h, int channels, uint16_t* const top[8], int ntop, int outw,
+                           int outh, int outcstep, int pad_top, int pad_left, int crop_x, int crop_y, uint16_t* alpha,
+                           int alphaw, int alphah, int bgr, hipStream_t st);
+void launch_postproc_shader(const uint16_t* const bottom[8], int nbottom, int w, int h, int cstep, const uint16_t* alpha,
+                            int alphaw, int alphah, uint8_t* top, int outw, int outh, int offset_x, int gx_max, int crop_x,
+                            int crop_y, int channels, int bgr, hipStream_t st);
+
+// planar fp16 [3][h][w]  <->  plane [h][w][32] (net_forward test hook)
+void launch_planar3_to_plane(const uint16_t* planar, int w, int h, void* plane, hipStream_t st);
+
+} // namespace rsr

@@ -1,0 +1,614 @@
+// kernels.hip -- gfx950 (CDNA4 / MI355X) kernels of the RealSR x4 hot path.
+//
+//   conv3x3_mfma<NT,UPS>   the 351 3x3 convolutions of models-DF2K*/x4.param as MFMA implicit GEMM
+//                          (v_mfma_f32_32x32x16_f16, fp32 accumulate), with bias / LeakyReLU /
+//                          residual-axpy epilogues fused (the graph's Eltwise, BinaryOp, Concat,
+//                          Split and Interp layers never exist as kernels).
+//   preproc_tiles          realsr_preproc{,_tta}.comp equivalent, writes the network input planes
+//   postproc_tiles         realsr_postproc{,_tta}.comp equivalent, writes the uint8 HWC image
+//   *_shader               the same arithmetic in the shaders' own memory layout (parity tests)
+//
+// Written for gfx950 only: 64-wide wavefronts, 160 KiB LDS, MFMA 32x32x16 f16.
+#include "kernels.h"
+
+namespace rsr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// =============================================================================================
+// conv3x3 (stride 1, zero pad 1) as implicit GEMM on the matrix cores
+// =============================================================================================
+//
+//   D[cout][pixel] += W[cout][k] * X[k][pixel],   k = (tap, cin)
+//
+// MFMA operand roles: A = weights (32 cout x 16 k), B = activations (16 k x 32 pixels), so that the
+// accumulator of a lane holds 16 output channels of ONE pixel (col = lane&31 = pixel,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = cout): the epilogue packs 4 consecutive channels into
+// one 8-byte fp16 store into the [H][W][32] plane.
+//
+// Workgroup = 4 waves, output block 16 rows x 32 cols.  Wave w owns rows 4w..4w+3 (R = 4 M-tiles of
+// 32 pixels) for all NT*32 output channels.  K is walked one 32-channel plane ("chunk") at a time:
+//   stage   the (16+2) x (32+2) pixel patch of the plane (64 B/pixel) and the chunk's weight image
+//           [9 taps][NT*32 cout][32 cin] into LDS,
+//   compute for dx in 0..2, for 16-channel half cb: read the 6 patch rows a wave needs ONCE and
+//           reuse each row fragment for the three dy taps (row r+dy of tap dy == row of tap 0):
+//           6 X + 3*NT W ds_read_b128 feed 12*NT MFMAs.
+// LDS layout: 64-B rows (pixel or weight row), the four 16-B slots of row i XOR-swizzled with
+// (i>>2)&3 -- ds_read_b128 lane groups (16 lanes) then touch 16 distinct 16-B bank groups for any
+// run of consecutive rows, i.e. conflict-free for every tap shift.
+//
+// Nearest-x2 upsampling (ncnn Interp type 1, x4.param:996,998) is folded into the staging address:
+// UPS kernels stage patch pixel (y,x) from source pixel (y>>1, x>>1).
+
+constexpr int kThreads = 256;
+constexpr int kPatchItems = kPatchPx * 4; // 16-byte items in the patch (2448)
+constexpr int kPatchIters = (kPatchItems + kThreads - 1) / kThreads; // 10
+
+__device__ __forceinline__ const char* plane_ptr(const PlaneSrc& s, int slot, int plane)
+{
+    return static_cast<const char*>(s.base) + (long long)slot * s.slot_stride + (long long)plane * s.plane_stride;
+}
+
+// DMA = true: both LDS images are filled by LDS-DMA (global_load_lds_dwordx4: per-lane global source,
+// wave-uniform LDS base + lane*16 destination), so staging costs no VGPRs and no ds_write; the XOR
+// swizzle is applied on the SOURCE address (LDS item i receives logical slot (i&3)^((i>>4)&3) of
+// pixel i>>2) and out-of-image pixels read a 16-byte zero page.  DMA = false: the same image built
+// through registers (global_load_dwordx4 + ds_write_b128).
+template <int NT, bool UPS, bool DMA>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WROWS = 9 * NT * 32;          // weight rows per chunk
+    constexpr int WITEMS = WROWS * 4;           // 16-byte items
+    constexpr int WITERS = (WITEMS + kThreads - 1) / kThreads;
+    constexpr int WOFF = kPatchLds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware work mapping: workgroup b runs on XCD b%8 (observed dispatch rule); give every XCD a
+    // contiguous run of work items (= neighbouring blocks of the same tiles) so halo rows and the
+    // weight images are re-read from that XCD's own L2.
+    const int per = (a.nitems + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (item >= a.nitems) return;
+    const WorkItem it = a.items[item];
+    const int slot = it.slot, y0 = it.y0, x0 = it.x0;
+    const TileDim td = a.dims[slot];
+    const int H = td.h << a.lvl_out, W = td.w << a.lvl_out; // output dims
+    const int Wi = td.w << a.lvl_in;                        // input row pitch in pixels
+
+    // ---- staging addresses (chunk invariant) ----
+    int srcoff[kPatchIters]; // byte offset inside a plane, -1 = zero fill
+    int dstoff[kPatchIters];
+#pragma unroll
+    for (int i = 0; i < kPatchIters; i++)
+    {
+        const int j = tid + i * kThreads;
+        const int px = j >> 2, sl = j & 3;
+        const int r = px / kPatchW, c = px - r * kPatchW;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        const bool ok = (j < kPatchItems) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int sy = UPS ? (gy >> 1) : gy, sx = UPS ? (gx >> 1) : gx;
+        if (DMA)
+        { // LDS item j is written linearly; it must receive logical slot sl ^ swz
+            srcoff[i] = ok ? ((sy * Wi + sx) * 64 + ((sl ^ ((px >> 2) & 3)) << 4)) : -1;
+            dstoff[i] = 0;
+        }
+        else
+        {
+            srcoff[i] = ok ? ((sy * Wi + sx) * 64 + sl * 16) : -1;
+            dstoff[i] = (j < kPatchItems) ? (px * 64 + ((sl ^ ((px >> 2) & 3)) << 4)) : -1;
+        }
+    }
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[r][n][e] = 0.f;
+
+    const int nplanes = a.n0 + a.n1;
+    const char* wbase = static_cast<const char*>(a.wpk);
+
+    for (int ck = 0; ck < nplanes; ck++)
+    {
+        const char* plane = (ck < a.n0) ? plane_ptr(a.src0, slot, ck) : plane_ptr(a.src1, slot, ck - a.n0);
+        const char* wsrc = wbase + (long long)ck * (WROWS * 64);
+
+        if (DMA)
+        {
+            __syncthreads(); // previous chunk's LDS reads are done
+            const char* zp = static_cast<const char*>(a.zeros);
+#pragma unroll
+            for (int i = 0; i < kPatchIters; i++)
+            {
+                const char* src = srcoff[i] >= 0 ? plane + srcoff[i] : zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + (i * kThreads + wave * 64) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WITERS; i++)
+            {
+                const int jw = i * kThreads + wave * 64; // wave-uniform first item
+                if (jw < WITEMS)                         // WITEMS is a multiple of 64
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (jw + lane) * 16),
+                                                     (__attribute__((address_space(3))) void*)(smem + WOFF + jw * 16), 16, 0, 0);
+            }
+            __syncthreads(); // hipcc drains vmcnt(0) (pending LDS-DMA) before the barrier
+        }
+        else
+        {
+            // global -> registers
+            uint4 pv[kPatchIters];
+#pragma unroll
+            for (int i = 0; i < kPatchIters; i++)
+            {
+                pv[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (srcoff[i] >= 0) pv[i] = *reinterpret_cast<const uint4*>(plane + srcoff[i]);
+            }
+            uint4 wv[WITERS];
+#pragma unroll
+            for (int i = 0; i < WITERS; i++)
+            {
+                const int j = tid + i * kThreads;
+                wv[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (j < WITEMS) wv[i] = *reinterpret_cast<const uint4*>(wsrc + j * 16);
+            }
+            __syncthreads(); // previous chunk's LDS reads are done
+#pragma unroll
+            for (int i = 0; i < kPatchIters; i++)
+                if (dstoff[i] >= 0) *reinterpret_cast<uint4*>(smem + dstoff[i]) = pv[i];
+#pragma unroll
+            for (int i = 0; i < WITERS; i++)
+            {
+                const int j = tid + i * kThreads;
+                if (j < WITEMS) *reinterpret_cast<uint4*>(smem + WOFF + j * 16) = wv[i];
+            }
+            __syncthreads();
+        }
+
+        // ---- MFMA ----
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+        {
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++)
+            {
+                const int ks = cb * 2 + hi;
+                half8 X[6];
+#pragma unroll
+                for (int rr = 0; rr < 6; rr++)
+                {
+                    const int p = (wave * 4 + rr) * kPatchW + l32 + dx;
+                    X[rr] = *reinterpret_cast<const half8*>(smem + p * 64 + ((ks ^ ((p >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++)
+                {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                    {
+                        const int row = (dy * 3 + dx) * (NT * 32) + nt * 32 + l32;
+                        const half8 Wf = *reinterpret_cast<const half8*>(smem + WOFF + row * 64 + ((ks ^ ((row >> 2) & 3)) << 4));
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++)
+                            acc[rr][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf, X[rr + dy], acc[rr][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    const int x = x0 + l32;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+    {
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(a.bias + nt * 32 + q * 8 + hi * 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+        {
+            const int y = y0 + wave * 4 + rr;
+            if (y >= H || x >= W) continue;
+            const long long pix = (long long)y * W + x;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                const int c0 = q * 8 + hi * 4; // channel within the 32-plane
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    float t = acc[rr][nt][q * 4 + e] + bq[q][e];
+                    if (a.lrelu) t = t > 0.f ? t : t * 0.2f;
+                    v[e] = t;
+                }
+                if (a.res1_kind == 2)
+                {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(plane_ptr(a.res1, slot, nt) + (pix * 32 + c0) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s1 + r[e];
+                }
+                else if (a.res1_kind == 1)
+                {
+                    const half4 r = *reinterpret_cast<const half4*>(plane_ptr(a.res1, slot, nt) + (pix * 32 + c0) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s1 + (float)r[e];
+                }
+                if (a.res2_kind == 2)
+                {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(plane_ptr(a.res2, slot, nt) + (pix * 32 + c0) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s2 + r[e];
+                }
+                else if (a.res2_kind == 1)
+                {
+                    const half4 r = *reinterpret_cast<const half4*>(plane_ptr(a.res2, slot, nt) + (pix * 32 + c0) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s2 + (float)r[e];
+                }
+                if (a.out16.base)
+                {
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
+                    *reinterpret_cast<half4*>(const_cast<char*>(plane_ptr(a.out16, slot, nt)) + (pix * 32 + c0) * 2) = o;
+                }
+                if (a.out32a.base)
+                    *reinterpret_cast<f32x4*>(const_cast<char*>(plane_ptr(a.out32a, slot, nt)) + (pix * 32 + c0) * 4) = v;
+                if (a.out32b.base)
+                    *reinterpret_cast<f32x4*>(const_cast<char*>(plane_ptr(a.out32b, slot, nt)) + (pix * 32 + c0) * 4) = v;
+                if (a.out_planar3 && nt == 0 && q == 0 && hi == 0)
+                {
+                    _Float16* o = reinterpret_cast<_Float16*>(static_cast<char*>(a.out_planar3) + (long long)slot * a.planar3_slot_stride);
+                    const long long hw = (long long)H * W;
+                    o[pix] = (_Float16)v[0];
+                    o[hw + pix] = (_Float16)v[1];
+                    o[2 * hw + pix] = (_Float16)v[2];
+                }
+            }
+        }
+    }
+}
+
+template <int NT, bool UPS, bool DMA>
+static void launch_conv_t(const ConvArgs& a, hipStream_t st)
+{
+    const int per = (a.nitems + 7) / 8;
+    const size_t lds = size_t(kPatchLds) + size_t(9 * NT * 32 * 64);
+    static bool attr_set = false; // > 64 KiB dynamic LDS needs the opt-in once per kernel
+    if (!attr_set)
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NT, UPS, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_mfma<NT, UPS, DMA>), dim3(per * 8), dim3(kThreads), lds, st, a);
+}
+
+void launch_conv(const ConvArgs& a, int nt, bool dma, hipStream_t st)
+{
+    if (a.nitems <= 0) return;
+    const bool ups = a.lvl_out != a.lvl_in;
+    const int key = (nt == 2 ? 4 : 0) | (ups ? 2 : 0) | (dma ? 1 : 0);
+    switch (key)
+    {
+    case 0: launch_conv_t<1, false, false>(a, st); break;
+    case 1: launch_conv_t<1, false, true>(a, st); break;
+    case 2: launch_conv_t<1, true, false>(a, st); break;
+    case 3: launch_conv_t<1, true, true>(a, st); break;
+    case 4: launch_conv_t<2, false, false>(a, st); break;
+    case 5: launch_conv_t<2, false, true>(a, st); break;
+    case 6: launch_conv_t<2, true, false>(a, st); break;
+    default: launch_conv_t<2, true, true>(a, st); break;
+    }
+}
+
+// =============================================================================================
+// pre / post processing
+// =============================================================================================
+
+// reflect-101 exactly as realsr_preproc.comp:59-62.  The shader's single reflection leaves the image
+// when the halo exceeds the image (n <= prepadding): the reference then reads out of bounds; here
+// the index is clamped (as the oracle does) so tiny images stay memory-safe and deterministic.
+__device__ __forceinline__ int reflect101(int v, int n)
+{
+    v = abs(v);
+    v = (n - 1) - abs(v - (n - 1));
+    return min(max(v, 0), n - 1);
+}
+
+// realsr_preproc.comp:47-95 and realsr_preproc_tta.comp:54-113, for a batch of tiles.
+// One thread per padded-tile pixel; writes the 32-channel fp16 input plane(s) (channels 3..31 = 0).
+// The band-relative coordinates of the shader (crop_x/crop_y/pad) are folded into x_org/y_org:
+// reflecting against the band equals reflecting against the image (engine.cpp explains why).
+__global__ __launch_bounds__(256) void preproc_tiles(const PreArgs a)
+{
+    const BaseTile t = a.tiles[blockIdx.z];
+    const int gx = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int gy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (gx >= t.tw || gy >= t.th) return;
+    const int x = reflect101(gx + t.x_org, a.w);
+    const int y = reflect101(gy + t.y_org, a.h);
+    const uint8_t* p = a.img + ((long long)y * a.w + x) * a.c;
+    const float norm_val = 1 / 255.f;
+    const int i0 = a.bgr ? 2 : 0, i2 = a.bgr ? 0 : 2;
+    half8 v0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v0[e] = (_Float16)0.f;
+    v0[0] = (_Float16)((float)p[i0] * norm_val);
+    v0[1] = (_Float16)((float)p[1] * norm_val);
+    v0[2] = (_Float16)((float)p[i2] * norm_val);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    const int nv = a.tta ? 8 : 1;
+    for (int k = 0; k < nv; k++)
+    {
+        int oy, ox, ow;
+        switch (k)
+        { // realsr_preproc_tta.comp:104-111
+        default: oy = gy; ox = gx; ow = t.tw; break;
+        case 1: oy = gy; ox = t.tw - 1 - gx; ow = t.tw; break;
+        case 2: oy = t.th - 1 - gy; ox = t.tw - 1 - gx; ow = t.tw; break;
+        case 3: oy = t.th - 1 - gy; ox = gx; ow = t.tw; break;
+        case 4: oy = gx; ox = gy; ow = t.th; break;
+        case 5: oy = gx; ox = t.th - 1 - gy; ow = t.th; break;
+        case 6: oy = t.tw - 1 - gx; ox = t.th - 1 - gy; ow = t.th; break;
+        case 7: oy = t.tw - 1 - gx; ox = gy; ow = t.th; break;
+        }
+        char* dst = static_cast<char*>(a.in_plane) + (long long)(t.slot0 + k) * a.slot_stride + ((long long)oy * ow + ox) * 64;
+        *reinterpret_cast<half8*>(dst) = v0;
+        *reinterpret_cast<uint4*>(dst + 16) = z;
+        *reinterpret_cast<uint4*>(dst + 32) = z;
+        *reinterpret_cast<uint4*>(dst + 48) = z;
+    }
+}
+
+void launch_preproc_tiles(const PreArgs& a, int max_tw, int max_th, hipStream_t st)
+{
+    if (a.ntiles <= 0) return;
+    const dim3 grid((max_tw + 31) / 32, (max_th + 7) / 8, a.ntiles), block(256);
+    hipLaunchKernelGGL(preproc_tiles, grid, block, 0, st, a);
+}
+
+// store conversion of realsr_postproc.comp:71-78 (v + 0.5, floor, clamp 0..255); negative values
+// saturate to 0 as on the reference CPU path (GLSL uint(floor(v)) is undefined there).
+__device__ __forceinline__ uint8_t post_store(float v)
+{
+    v = floorf(v + 0.5f);
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    return (uint8_t)v;
+}
+
+// ncnn Interp bicubic coefficients (alpha channel only; realsr.cpp:128-140)
+__device__ __forceinline__ void cubic_coeffs(int w, int outw, int dx, int& sx, float c[4])
+{
+    const float scale = (float)w / (float)outw;
+    float fx = ((float)dx + 0.5f) * scale - 0.5f;
+    sx = (int)floorf(fx);
+    fx -= (float)sx;
+    const float A = -0.75f;
+    const float fx0 = fx + 1.f, fx1 = fx, fx2 = 1.f - fx;
+    c[0] = A * fx0 * fx0 * fx0 - 5.f * A * fx0 * fx0 + 8.f * A * fx0 - 4.f * A;
+    c[1] = (A + 2.f) * fx1 * fx1 * fx1 - (A + 3.f) * fx1 * fx1 + 1.f;
+    c[2] = (A + 2.f) * fx2 * fx2 * fx2 - (A + 3.f) * fx2 * fx2 + 1.f;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+    if (sx <= -1) { sx = 1; c[0] = 1.f - c[3]; c[1] = c[3]; c[2] = 0.f; c[3] = 0.f; }
+    if (sx == 0) { sx = 1; c[0] = c[0] + c[1]; c[1] = c[2]; c[2] = c[3]; c[3] = 0.f; }
+    if (sx == w - 2) { sx = w - 3; c[3] = c[2] + c[3]; c[2] = c[1]; c[1] = c[0]; c[0] = 0.f; }
+    if (sx >= w - 1) { sx = w - 3; c[3] = 1.f - c[0]; c[2] = c[0]; c[1] = 0.f; c[0] = 0.f; }
+}
+
+__device__ __forceinline__ int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
+
+// realsr_postproc.comp:47-89 and realsr_postproc_tta.comp:54-110 for a batch of tiles.
+// One thread per output pixel of the tile's un-padded x4 rectangle.
+__global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
+{
+    const BaseTile t = a.tiles[blockIdx.z];
+    const int gx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int gy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (gx >= t.out_w || gy >= t.out_h) return;
+    const int w = t.tw * 4, h = t.th * 4;
+    const long long cstep = (long long)w * h;
+    const int sx = gx + a.crop, sy = gy + a.crop;
+    uint8_t* o = a.out + ((long long)(t.out_y + gy) * a.out_w + t.out_x + gx) * a.c;
+    const _Float16* b0 = reinterpret_cast<const _Float16*>(static_cast<const char*>(a.planar3) + (long long)t.slot0 * a.slot_stride);
+    float v[3];
+    if (!a.tta)
+    {
+#pragma unroll
+        for (int q = 0; q < 3; q++) v[q] = (float)b0[q * cstep + (long long)sy * w + sx];
+    }
+    else
+    {
+        const long long ss = a.slot_stride / 2;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+        {
+            const _Float16* b = b0 + q * cstep;
+            // realsr_postproc_tta.comp:76-85
+            const float v0 = (float)b[(long long)sy * w + sx];
+            const float v1 = (float)b[ss + (long long)sy * w + (w - 1 - sx)];
+            const float v2 = (float)b[2 * ss + (long long)(h - 1 - sy) * w + (w - 1 - sx)];
+            const float v3 = (float)b[3 * ss + (long long)(h - 1 - sy) * w + sx];
+            const float v4 = (float)b[4 * ss + (long long)sx * h + sy];
+            const float v5 = (float)b[5 * ss + (long long)sx * h + (h - 1 - sy)];
+            const float v6 = (float)b[6 * ss + (long long)(w - 1 - sx) * h + (h - 1 - sy)];
+            const float v7 = (float)b[7 * ss + (long long)(w - 1 - sx) * h + sy];
+            v[q] = (v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7) * 0.125f;
+        }
+    }
+    const uint8_t r = post_store(v[0] * 255.f), g = post_store(v[1] * 255.f), bl = post_store(v[2] * 255.f);
+    o[a.bgr ? 2 : 0] = r;
+    o[1] = g;
+    o[a.bgr ? 0 : 2] = bl;
+    if (a.c == 4)
+    {
+        // alpha: bicubic x4 of the un-padded tile's alpha (0..255 units), realsr.cpp:431-442,
+        // realsr_preproc.comp:79-88 (crop), realsr_postproc.comp:58-61
+        const int aw = t.out_w / 4, ah = t.out_h / 4;
+        const int ax0 = t.out_x / 4, ay0 = t.out_y / 4;
+        int bx, by;
+        float cx[4], cy[4];
+        cubic_coeffs(aw, t.out_w, gx, bx, cx);
+        cubic_coeffs(ah, t.out_h, gy, by, cy);
+        float rows[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const int yy = ay0 + clampi(by - 1 + j, ah);
+            const uint8_t* rp = a.in_img + ((long long)yy * a.in_w + ax0) * 4 + 3;
+            rows[j] = (float)rp[clampi(bx - 1, aw) * 4] * cx[0] + (float)rp[clampi(bx, aw) * 4] * cx[1] +
+                      (float)rp[clampi(bx + 1, aw) * 4] * cx[2] + (float)rp[clampi(bx + 2, aw) * 4] * cx[3];
+        }
+        const float av = rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3];
+        o[3] = post_store(av);
+    }
+}
+
+void launch_postproc_tiles(const PostArgs& a, int max_ow, int max_oh, hipStream_t st)
+{
+    if (a.ntiles <= 0) return;
+    const dim3 grid((max_ow + 63) / 64, (max_oh + 3) / 4, a.ntiles), block(256);
+    hipLaunchKernelGGL(postproc_tiles, grid, block, 0, st, a);
+}
+
+// ---- shader-shaped kernels: same arithmetic, the shaders' own buffer layouts -----------------
+struct Ptr8
+{
+    uint16_t* p[8];
+};
+struct CPtr8
+{
+    const uint16_t* p[8];
+};
+
+__global__ __launch_bounds__(256) void preproc_shader(const uint8_t* bottom, int w, int h, int channels, Ptr8 top, int ntop,
+                                                      int outw, int outh, int outcstep, int pad_top, int pad_left,
+                                                      int crop_x, int crop_y, uint16_t* alpha, int alphaw, int alphah, int bgr)
+{
+    int gx = blockIdx.x * 32 + (threadIdx.x & 31);
+    int gy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const int gz = blockIdx.z;
+    if (gx >= outw || gy >= outh || gz >= channels) return;
+    int x = gx + crop_x - pad_left;
+    int y = gy + crop_y - pad_top;
+    x = reflect101(x, w);
+    y = reflect101(y, h);
+    const int v_offset = y * w + x;
+    float v;
+    if (bgr == 1 && gz != 3) v = (float)bottom[v_offset * channels + 2 - gz];
+    else v = (float)bottom[v_offset * channels + gz];
+    if (gz == 3)
+    {
+        gx -= pad_left;
+        gy -= pad_top;
+        if (alpha && gx >= 0 && gx < alphaw && gy >= 0 && gy < alphah)
+            reinterpret_cast<_Float16*>(alpha)[gy * alphaw + gx] = (_Float16)v;
+        return;
+    }
+    const float norm_val = 1 / 255.f;
+    const _Float16 hv = (_Float16)(v * norm_val);
+    const int gzi = gz * outcstep;
+    _Float16* const* T = reinterpret_cast<_Float16* const*>(top.p);
+    T[0][gzi + gy * outw + gx] = hv;
+    if (ntop == 8)
+    {
+        T[1][gzi + gy * outw + (outw - 1 - gx)] = hv;
+        T[2][gzi + (outh - 1 - gy) * outw + (outw - 1 - gx)] = hv;
+        T[3][gzi + (outh - 1 - gy) * outw + gx] = hv;
+        T[4][gzi + gx * outh + gy] = hv;
+        T[5][gzi + gx * outh + (outh - 1 - gy)] = hv;
+        T[6][gzi + (outw - 1 - gx) * outh + (outh - 1 - gy)] = hv;
+        T[7][gzi + (outw - 1 - gx) * outh + gy] = hv;
+    }
+}
+
+void launch_preproc_shader(const uint8_t* bottom, int w, int h, int channels, uint16_t* const top[8], int ntop, int outw,
+                           int outh, int outcstep, int pad_top, int pad_left, int crop_x, int crop_y, uint16_t* alpha,
+                           int alphaw, int alphah, int bgr, hipStream_t st)
+{
+    Ptr8 t;
+    for (int i = 0; i < 8; i++) t.p[i] = i < ntop ? top[i] : nullptr;
+    const dim3 grid((outw + 31) / 32, (outh + 7) / 8, channels), block(256);
+    hipLaunchKernelGGL(preproc_shader, grid, block, 0, st, bottom, w, h, channels, t, ntop, outw, outh, outcstep, pad_top,
+                       pad_left, crop_x, crop_y, alpha, alphaw, alphah, bgr);
+}
+
+__global__ __launch_bounds__(256) void postproc_shader(CPtr8 bottom, int nbottom, int w, int h, int cstep, const uint16_t* alpha,
+                                                       int alphaw, int alphah, uint8_t* top, int outw, int outh, int offset_x,
+                                                       int gx_max, int crop_x, int crop_y, int channels, int bgr)
+{
+    const int gx = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int gy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const int gz = blockIdx.z;
+    if (gx >= gx_max || gy >= outh || gz >= channels) return;
+    const _Float16* const* B = reinterpret_cast<const _Float16* const*>(bottom.p);
+    float v;
+    if (gz == 3) v = (float)reinterpret_cast<const _Float16*>(alpha)[gy * alphaw + gx];
+    else
+    {
+        const int gzi = gz * cstep;
+        const int sy = gy + crop_y, sx = gx + crop_x;
+        if (nbottom == 1) v = (float)B[0][gzi + sy * w + sx];
+        else
+        {
+            const float v0 = (float)B[0][gzi + sy * w + sx];
+            const float v1 = (float)B[1][gzi + sy * w + (w - 1 - sx)];
+            const float v2 = (float)B[2][gzi + (h - 1 - sy) * w + (w - 1 - sx)];
+            const float v3 = (float)B[3][gzi + (h - 1 - sy) * w + sx];
+            const float v4 = (float)B[4][gzi + sx * h + sy];
+            const float v5 = (float)B[5][gzi + sx * h + (h - 1 - sy)];
+            const float v6 = (float)B[6][gzi + (w - 1 - sx) * h + (h - 1 - sy)];
+            const float v7 = (float)B[7][gzi + (w - 1 - sx) * h + sy];
+            v = (v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7) * 0.125f;
+        }
+        v = v * 255.f;
+    }
+    const int v_offset = gy * outw + gx + offset_x;
+    const uint8_t u = post_store(v);
+    if (bgr == 1 && gz != 3) top[v_offset * channels + 2 - gz] = u;
+    else top[v_offset * channels + gz] = u;
+}
+
+void launch_postproc_shader(const uint16_t* const bottom[8], int nbottom, int w, int h, int cstep, const uint16_t* alpha,
+                            int alphaw, int alphah, uint8_t* top, int outw, int outh, int offset_x, int gx_max, int crop_x,
+                            int crop_y, int channels, int bgr, hipStream_t st)
+{
+    CPtr8 b;
+    for (int i = 0; i < 8; i++) b.p[i] = i < nbottom ? bottom[i] : nullptr;
+    const dim3 grid((gx_max + 31) / 32, (outh + 7) / 8, channels), block(256);
+    hipLaunchKernelGGL(postproc_shader, grid, block, 0, st, b, nbottom, w, h, cstep, alpha, alphaw, alphah, top, outw, outh,
+                       offset_x, gx_max, crop_x, crop_y, channels, bgr);
+}
+
+__global__ __launch_bounds__(256) void planar3_to_plane(const uint16_t* planar, int w, int h, void* plane)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)w * h) return;
+    const long long hw = (long long)w * h;
+    uint4 v0 = make_uint4(0u, 0u, 0u, 0u);
+    v0.x = (uint32_t)planar[i] | ((uint32_t)planar[hw + i] << 16);
+    v0.y = (uint32_t)planar[2 * hw + i];
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    uint4* d = reinterpret_cast<uint4*>(static_cast<char*>(plane) + i * 64);
+    d[0] = v0;
+    d[1] = z;
+    d[2] = z;
+    d[3] = z;
+}
+
+void launch_planar3_to_plane(const uint16_t* planar, int w, int h, void* plane, hipStream_t st)
+{
+    const long long n = (long long)w * h;
+    hipLaunchKernelGGL(planar3_to_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, planar, w, h, plane);
+}
+
+} // namespace rsr

@@ -1,0 +1,89 @@
+// model.h -- ncnn .param/.bin reader, graph validation and weight packing (host only, no HIP).
+//
+// Replaces what the reference gets from ncnn::Net::load_param / load_model
+// (/root/reference/src/realsr.cpp:75-76) for the one graph it ships:
+// models/models-DF2K*/x4.param = ESRGAN RRDBNet(in 3, out 3, nf 64, nb 23, gc 32), 999 layers.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rsr {
+
+struct ParamLayer
+{
+    std::string type, name;
+    std::vector<std::string> bottoms, tops;
+    // scalar params by id, array params by id (id = -23300 - key)
+    std::vector<std::pair<int, std::string>> scalars;
+    std::vector<std::pair<int, std::vector<float>>> arrays;
+    int geti(int id, int def) const;
+    float getf(int id, float def) const;
+    const std::vector<float>* geta(int id) const;
+};
+
+struct ConvRec
+{
+    int cin = 0, cout = 0;
+    int act = 0; // 0 none, 2 leakyrelu
+    float slope = 0.f;
+    std::vector<float> weight; // OIHW
+    std::vector<float> bias;
+};
+
+struct Model
+{
+    int n_layers = 0, n_blobs = 0;
+    std::vector<ParamLayer> layers;
+    std::vector<ConvRec> convs; // file order == canonical RRDBNet order (validated)
+    int bin_encoding = -1;      // 1 fp16-tagged, 0 raw fp32, 2 mixed/table
+    long long n_weights = 0, n_biases = 0;
+};
+
+// Network constants of the validated graph
+constexpr int kNumRRDB = 23;
+constexpr int kNumRDB = kNumRRDB * 3; // 69
+constexpr int kNumConvs = 1 + kNumRDB * 5 + 5; // 351
+constexpr int kNF = 64, kGC = 32;
+
+// Error codes match include/realsr_hip.h
+int parse_param(const std::string& path, Model& m, std::string& err);
+int validate_graph(const Model& m, std::string& err); // checks DAG == canonical RRDBNet, fills nothing
+int read_bin(const std::string& path, Model& m, std::string& err);
+int load_model(const std::string& param, const std::string& bin, Model& m, std::string& err);
+
+// ---- packed blob ---------------------------------------------------------------------------
+// One relocatable byte blob holding every conv's weights in the exact LDS image the MFMA kernel
+// stages (see kernels.hip): per conv, per 32-input-channel chunk:
+//     [tap 0..8][cout row 0..NT*32-1][32 cin] fp16, 64 B per row, the four 16-B slots of a row
+//     XOR-swizzled with ((row_index >> 2) & 3), row_index = tap*NT*32 + cout
+// followed by NT*32 fp32 biases.  Cin is zero-padded to a multiple of 32 (conv_first 3 -> 32),
+// Cout to a multiple of 32 (conv_last 3 -> 32).
+struct PackedHeader
+{
+    uint32_t magic;   // 'RSRP'
+    uint32_t version; // 1
+    uint32_t nconv;
+    uint32_t reserved;
+    uint64_t total_bytes;
+};
+struct PackedConv
+{
+    uint32_t cin, cout;     // true channel counts
+    uint32_t act;           // 0 / 2
+    uint32_t nplanes;       // ceil(cin/32)
+    uint32_t nt;            // ceil(cout/32)
+    float slope;
+    uint64_t w_off, b_off;  // byte offsets from blob start (256-B aligned)
+};
+constexpr uint32_t kPackedMagic = 0x50525352u; // "RSRP"
+
+size_t packed_size(const Model& m);
+int pack_model(const Model& m, void* dst, size_t cap, std::string& err);
+int check_packed(const void* blob, size_t bytes, std::string& err);
+
+uint16_t f32_to_f16(float f);
+float f16_to_f32(uint16_t h);
+
+} // namespace rsr

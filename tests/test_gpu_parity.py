@@ -1,0 +1,243 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Everything goes through the C-ABI
+(librealsr_hip.so via ctypes); the oracle is only the checker.
+
+Tolerances (BASELINE.json north_star): final uint8 within +-1 per channel of the CPU path at the same
+tile size; pre-quantise fp error reported and bounded (stated per test)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import realsr_ncnn_vulkan_amd as R
+from realsr_ncnn_vulkan_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def paths(model_dir):
+    return os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin")
+
+
+@pytest.fixture(scope="module")
+def sr(paths):
+    s = R.RealSR(0)
+    s.load(*paths)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def sr_tta(paths):
+    s = R.RealSR(0, tta_mode=True)
+    s.load(*paths)
+    yield s
+    s.close()
+
+
+def test_native_library_is_the_one_loaded(sr):
+    maps = open("/proc/self/maps").read()
+    assert "librealsr_hip.so" in maps
+
+
+# ---- layer level ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,h,w,ups", [(64, 32, 20, 40, False), (96, 32, 17, 33, False), (128, 32, 16, 32, False),
+                                              (160, 32, 33, 65, False), (192, 64, 16, 32, False), (3, 64, 9, 70, False),
+                                              (64, 3, 33, 31, False), (64, 64, 10, 21, True), (64, 64, 1, 1, False)])
+@pytest.mark.parametrize("lrelu", [False, True])
+def test_conv3x3_layer_matches_oracle(sr, cin, cout, h, w, ups, lrelu):
+    """fp16 inputs/weights, fp32 accumulate vs the oracle's fp32 conv on the same rounded operands:
+    only accumulation order + the final fp16 rounding differ -> |d| <= 2^-10 * |ref| + 1e-3."""
+    rng = np.random.default_rng(cin * 1000 + cout + h)
+    x = rng.standard_normal((cin, h, w)).astype(np.float16)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    xr = x.astype(np.float32)
+    if ups:
+        xr = xr.repeat(2, axis=1).repeat(2, axis=2)
+    ref = oracle.conv3x3(xr, wt, b, 2 if lrelu else 0, 0.2)
+    for dma in (1, 0):
+        sr.set_option("use_dma", dma)
+        got = sr.conv3x3(x, wt, b, lrelu=lrelu, upsample2x=ups).astype(np.float32)
+        assert got.shape == ref.shape
+        assert (np.abs(got - ref) <= np.abs(ref) * 2.0 ** -10 + 1e-3).all(), "dma=%d max err %g" % (dma, np.abs(got - ref).max())
+    sr.set_option("use_dma", 1)
+
+
+# ---- the four shaders: bit exact --------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,c", [(50, 43, 3), (50, 43, 4), (7, 9, 3), (200, 37, 3), (33, 64, 3)])
+def test_preproc_kernels_bit_exact(sr, w, h, c):
+    rng = np.random.default_rng(w * h + c)
+    img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    T, P = 32, 10
+    for yi in range((h + T - 1) // T):
+        y0, y1 = max(yi * T - P, 0), min((yi + 1) * T + P, h)
+        band = np.ascontiguousarray(img[y0:y1])
+        for xi in range((w + T - 1) // T):
+            twn = min((xi + 1) * T, w) - xi * T
+            thn = min((yi + 1) * T, h) - yi * T
+            tw, th = twn + 2 * P, thn + 2 * P
+            a = (P, P, xi * T, min(yi * T, P))  # pad_top, pad_left, crop_x, crop_y: realsr.cpp:401-404
+            if c == 4:
+                r1, al1 = oracle.preproc(band, tw, th, *a, alphaw=twn, alphah=thn)
+                r2, al2 = sr.preproc(band, tw, th, *a, alphaw=twn, alphah=thn)
+                assert (al1.view(np.uint16) == al2.view(np.uint16)).all()
+            else:
+                r1 = oracle.preproc(band, tw, th, *a)
+                r2 = sr.preproc(band, tw, th, *a)
+                t1 = oracle.preproc_tta(band, tw, th, *a)
+                t2 = sr.preproc_tta(band, tw, th, *a)
+                for k in range(8):
+                    assert (t1[k].view(np.uint16) == t2[k].view(np.uint16)).all(), "tta blob %d" % k
+            assert (r1.view(np.uint16) == r2.view(np.uint16)).all()
+
+
+@pytest.mark.parametrize("c", [3, 4])
+def test_postproc_kernel_bit_exact(sr, c):
+    rng = np.random.default_rng(c)
+    tw, th, twn, thn = 30, 26, 10, 6
+    bot = (rng.standard_normal((3, th * 4, tw * 4)) * 0.6 + 0.5).astype(np.float16)  # over/undershoots [0,1]
+    alpha = (rng.random((thn * 4, twn * 4)) * 300 - 20).astype(np.float16) if c == 4 else None
+    o1 = rng.integers(0, 256, (thn * 4, 100, c), dtype=np.uint8)
+    o2 = o1.copy()
+    oracle.postproc(bot, o1, 12, twn * 4, 40, 40, alpha=alpha)
+    sr.postproc(bot, o2, 12, twn * 4, 40, 40, alpha=alpha)
+    assert (o1 == o2).all()
+    assert (o1[:, :12] == o2[:, :12]).all() and (o1[:, 52:] == o2[:, 52:]).all()  # untouched columns kept
+
+
+def test_postproc_tta_kernel(sr):
+    rng = np.random.default_rng(8)
+    bots = [(rng.standard_normal((3, 104, 120) if k < 4 else (3, 120, 104)) * 0.6 + 0.5).astype(np.float16) for k in range(8)]
+    o1 = rng.integers(0, 256, (24, 100, 3), dtype=np.uint8)
+    o2 = o1.copy()
+    oracle.postproc_tta(bots, o1, 12, 40, 40, 40)
+    sr.postproc_tta(bots, o2, 12, 40, 40, 40)
+    assert (o1 == o2).all()  # same fp32 sum order as the shader (v0+...+v7)*0.125
+
+
+# ---- network on one tile ------------------------------------------------------------------------------
+@pytest.mark.parametrize("trunk_fp32", [1, 0])
+def test_network_tile_prequantise_error(sr, oracle_net, trunk_fp32):
+    """Pre-quantise error of the `output` blob in [0,1] units.  Stated tolerance: max <= 4e-3,
+    p99.9 <= 2e-3 (fp16 storage / fp32 accumulate vs fp32 everywhere, 351 convs); uint8 +-1."""
+    img = synth.make_image(5, 44, 36)
+    x = (img.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)).astype(np.float16)
+    ref = oracle_net.forward(x.astype(np.float32))
+    sr.set_option("trunk_fp32", trunk_fp32)
+    try:
+        got = sr.net_forward(x).astype(np.float32)
+    finally:
+        sr.set_option("trunk_fp32", 1)
+    d = np.abs(got - ref)
+    print("trunk_fp32=%d max %.3e p99.9 %.3e mean %.3e" % (trunk_fp32, d.max(), np.quantile(d, 0.999), d.mean()))
+    assert d.max() <= 4e-3 and np.quantile(d, 0.999) <= 2e-3
+    q = lambda v: np.clip(np.floor(v * 255.0 + 0.5), 0, 255)
+    assert np.abs(q(got) - q(ref)).max() <= 1
+
+
+# ---- end to end through rsr_process ---------------------------------------------------------------------
+E2E = [(50, 43, 3, 32, False), (70, 20, 3, 64, False), (24, 20, 3, 200, False), (5, 3, 3, 32, False),
+       (33, 64, 3, 32, False), (37, 20, 4, 32, False), (40, 33, 3, 32, True), (21, 38, 4, 16, True)]
+
+
+@pytest.mark.parametrize("w,h,c,T,tta", E2E)
+def test_process_matches_oracle_within_one(sr, sr_tta, oracle_net, w, h, c, T, tta):
+    eng = sr_tta if tta else sr
+    eng.tilesize = T
+    img = synth.make_image(9 + w, w, h, c)
+    ref = oracle_net.process(img, T, tta=tta)
+    got = eng.process(img)
+    assert got.shape == ref.shape == (4 * h, 4 * w, c)
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert d.max() <= 1, "max diff %d at %s" % (d.max(), np.argwhere(d > 1)[:4])
+    assert (d > 0).mean() < 0.05
+
+
+def test_golden_fixtures(sr, sr_tta):
+    g = np.load(os.path.join(HERE, "golden", "cases.npz"))
+    names = sorted(k[:-4] for k in g.files if k.endswith("_cfg"))
+    assert len(names) >= 6
+    for n in names:
+        seed, w, h, c, T, tta = [int(v) for v in g[n + "_cfg"]]
+        eng = sr_tta if tta else sr
+        eng.tilesize = T
+        got = eng.process(g[n + "_in"])
+        d = np.abs(got.astype(int) - g[n + "_out"].astype(int))
+        assert d.max() <= 1, n
+
+
+def test_device_api_equals_host_api(sr):
+    import torch
+    sr.tilesize = 32
+    img = synth.make_image(77, 61, 47)
+    host = sr.process(img)
+    d_in = torch.from_numpy(img).cuda()
+    d_out = torch.zeros((47 * 4, 61 * 4, 3), dtype=torch.uint8, device="cuda")
+    sr.process_device(d_in.data_ptr(), 61, 47, 3, d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy() == host).all()
+
+
+def test_packed_blob_load_equals_file_load(paths, sr):
+    import torch
+    blob = R.model_pack(*paths)
+    img = synth.make_image(78, 40, 30)
+    sr.tilesize = 32
+    want = sr.process(img)
+    s2 = R.RealSR(0)
+    s2.load_packed(blob)
+    s2.tilesize = 32
+    assert (s2.process(img) == want).all()
+    s3 = R.RealSR(0)
+    dblob = torch.from_numpy(blob).cuda()
+    s3.load_packed(dblob.numel(), device_ptr=dblob.data_ptr())
+    s3.tilesize = 32
+    assert (s3.process(img) == want).all()
+    s2.close()
+    s3.close()
+
+
+def test_small_workspace_batches_give_identical_output(paths):
+    """Tile batches are an implementation detail: forcing 1-2 tiles per batch must not change a byte."""
+    img = synth.make_image(79, 90, 70)
+    a = R.RealSR(0)
+    a.load(*paths)
+    a.tilesize = 32
+    want = a.process(img)
+    a.set_option("max_workspace_mb", 40)
+    got = a.process(img)
+    a.close()
+    assert (got == want).all()
+
+
+def test_process_before_load_is_an_error():
+    s = R.RealSR(0)
+    with pytest.raises(R.RealSRError) as e:
+        s.process(np.zeros((8, 8, 3), np.uint8))
+    assert e.value.code == R.RSR_E_STATE
+    s.close()
+
+
+# ---- full BASELINE size: properties that need no oracle over the whole frame ---------------------------------
+def test_full_hd_properties(sr, oracle_net):
+    """C2 (1920x1080, T=200): determinism, tile locality, and one full-size tile against the oracle."""
+    sr.tilesize = 200
+    img = synth.make_image(3, 1920, 1080)
+    a = sr.process(img)
+    b = sr.process(img)
+    assert a.shape == (4320, 7680, 3)
+    assert (a == b).all()
+    # locality: a crop cut on tile boundaries reproduces the interior tiles bit for bit
+    sub = np.ascontiguousarray(img[200:800, 400:1000])
+    s = sr.process(sub)
+    assert (s[800:1600, 800:1600] == a[1600:2400, 2400:3200]).all()
+    # one full-size interior tile (padded 220x220) against the oracle network
+    P = 10
+    tile = img[400 - P:600 + P, 600 - P:800 + P].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+    ref = oracle_net.forward(tile)[:, 40:-40, 40:-40]
+    ref8 = np.clip((ref * 255.0 + 0.5).astype(np.int32), 0, 255).transpose(1, 2, 0)
+    d = np.abs(a[1600:2400, 2400:3200].astype(int) - ref8)
+    assert d.max() <= 1

@@ -1,0 +1,129 @@
+"""CPU tests of the host side of librealsr_hip.so: it loads, exports every symbol include/realsr_hip.h
+declares, parses/validates/packs the model; nothing here launches a kernel."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import realsr_ncnn_vulkan_amd as R
+from realsr_ncnn_vulkan_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "realsr_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = R.lib()
+    names = header_functions()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(L, n), "librealsr_hip.so does not export %s" % n
+    assert sorted(R.EXPORTS) == names
+    assert b"gfx950" in L.rsr_version()
+
+
+def test_library_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.check_output(["ldd", R.LIB_PATH]).decode()
+    assert "oracle" not in out
+    syms = subprocess.check_output(["nm", "-D", R.LIB_PATH]).decode()
+    assert "orc_" not in syms
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(R.RealSRError) as e:
+        R.RealSR(0)
+    assert e.value.code == R.RSR_E_DEVICE
+    assert "no CPU fallback" in str(e.value) or "device" in str(e.value)
+
+
+def test_model_info_both_encodings(model_dir, tmp_path, weights):
+    info = R.model_info(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
+    assert info == dict(n_layers=999, n_convs=351, n_weights=16684416, n_biases=13571, bin_encoding=1)
+    d = tmp_path / "models-DF2K_JPEG"
+    d.mkdir()
+    synth.write_param(str(d / "x4.param"))
+    synth.write_bin(str(d / "x4.bin"), weights, "fp32")
+    assert R.model_info(str(d / "x4.param"), str(d / "x4.bin"))["bin_encoding"] == 0
+
+
+def test_error_codes(model_dir, tmp_path):
+    pp, bp = os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin")
+    with pytest.raises(R.RealSRError) as e:
+        R.model_info(str(tmp_path / "missing.param"), bp)
+    assert e.value.code == R.RSR_E_IO
+    bad = tmp_path / "bad.param"
+    bad.write_text(open(pp).read().replace("7767517", "7767518", 1))
+    with pytest.raises(R.RealSRError) as e:
+        R.model_info(str(bad), bp)
+    assert e.value.code == R.RSR_E_FORMAT
+    # a graph that parses but is not the RRDBNet the fused schedule implements
+    txt = open(pp).read()
+    bad.write_text(txt.replace("-23310=1,2.000000e-01", "-23310=1,1.000000e-01", 1))
+    with pytest.raises(R.RealSRError) as e:
+        R.model_info(str(bad), bp)
+    assert e.value.code == R.RSR_E_GRAPH
+    lines = txt.split("\n")
+    # swap the operands of the first Eltwise: 0.2*x + 1.0*x5 is a different network
+    i = next(k for k, l in enumerate(lines) if l.startswith("Eltwise"))
+    f = lines[i].split()
+    f[4], f[5] = f[5], f[4]
+    bad.write_text("\n".join(lines[:i] + [" ".join(f)] + lines[i + 1:]))
+    with pytest.raises(R.RealSRError) as e:
+        R.model_info(str(bad), bp)
+    assert e.value.code == R.RSR_E_GRAPH
+    tb = tmp_path / "trunc.bin"
+    tb.write_bytes(open(bp, "rb").read()[:-100])
+    with pytest.raises(R.RealSRError) as e:
+        R.model_info(pp, str(tb))
+    assert e.value.code == R.RSR_E_IO
+
+
+def test_packed_blob_layout(model_dir, weights):
+    """Un-swizzle the packed LDS images and compare with the OIHW weights."""
+    blob = R.model_pack(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
+    magic, version, nconv, _ = np.frombuffer(blob[:16], np.uint32)
+    assert magic == 0x50525352 and version == 1 and nconv == 351
+    assert int(np.frombuffer(blob[16:24], np.uint64)[0]) == blob.size
+    rec = np.dtype([("cin", "<u4"), ("cout", "<u4"), ("act", "<u4"), ("nplanes", "<u4"), ("nt", "<u4"),
+                    ("slope", "<f4"), ("w_off", "<u8"), ("b_off", "<u8")])
+    assert rec.itemsize == 40
+    table = np.frombuffer(blob[24:24 + 351 * 40], rec)
+    specs = synth.conv_specs()
+    for i in (0, 1, 4, 5, 346, 349, 350):
+        t = table[i]
+        cin, cout, act = specs[i]
+        assert (t["cin"], t["cout"], t["act"]) == (cin, cout, act)
+        np_, nt = (cin + 31) // 32, (cout + 31) // 32
+        assert (t["nplanes"], t["nt"]) == (np_, nt)
+        rows = 9 * nt * 32
+        img = np.frombuffer(blob[int(t["w_off"]):int(t["w_off"]) + np_ * rows * 64], np.float16).reshape(np_, rows, 4, 8)
+        W, b = weights[i]
+        Wp = np.zeros((nt * 32, np_ * 32, 3, 3), np.float32)
+        Wp[:cout, :cin] = W
+        for ck in range(np_):
+            for row in (0, 5, 31, 37, rows - 1):
+                tap, n = divmod(row, nt * 32)
+                swz = (row >> 2) & 3
+                for slot in range(4):
+                    got = img[ck, row, slot ^ swz].astype(np.float32)
+                    want = Wp[n, ck * 32 + slot * 8: ck * 32 + slot * 8 + 8, tap // 3, tap % 3]
+                    assert (got == want).all(), (i, ck, row, slot)
+        bias = np.frombuffer(blob[int(t["b_off"]):int(t["b_off"]) + nt * 32 * 4], np.float32)
+        assert (bias[:cout] == b).all() and (bias[cout:] == 0).all()
+
+
+def test_shard_frames_partitions_exactly():
+    for n, ws in [(64, 8), (7, 4), (1, 2), (0, 3)]:
+        seen = sorted(i for r in range(ws) for i in R.shard_frames(n, ws, r))
+        assert seen == list(range(n))

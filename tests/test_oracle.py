@@ -1,0 +1,200 @@
+"""CPU tests of the oracle itself (oracle/realsr_oracle.c): it has no reference golden vectors to pin
+against (the reference ships none, SURVEY.md 8c -> "parity unpinned"), so it is pinned against
+independent constructions: numpy fp16, a PyTorch RRDBNet, a second tiling implementation written from
+realsr.cpp in numpy, and the committed golden outputs (drift guard)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from realsr_ncnn_vulkan_amd import synth
+from torch_ref import net_forward_np
+
+REF_PARAM = "/root/reference/models/models-DF2K/x4.param"
+
+
+def test_fp16_roundtrip_matches_numpy():
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.standard_normal(2000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1, 300, 7e4)])
+    xs = np.concatenate([xs, np.array([0.0, -0.0, 65504.0, 65520.0, 1e-7, 5.96e-8, 2.98e-8, np.inf, -np.inf], dtype=np.float32)])
+    L = oracle.lib()
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16)
+    got = np.array([L.orc_f32_to_f16(float(v)) for v in xs], dtype=np.uint16)
+    assert (got == want.view(np.uint16)).all()
+    back = np.array([L.orc_f16_to_f32(int(v)) for v in got], dtype=np.float32)
+    assert (back.view(np.uint32) == want.astype(np.float32).view(np.uint32)).all()
+
+
+def test_param_generator_equals_reference_file():
+    if not os.path.exists(REF_PARAM):
+        pytest.skip("reference checkout not present on this box")
+    assert synth.param_text() == open(REF_PARAM).read()
+    # both shipped model dirs carry the same graph
+    assert open(REF_PARAM).read() == open(REF_PARAM.replace("models-DF2K", "models-DF2K_JPEG")).read()
+
+
+def test_bin_size_matches_ncnn_layout(model_dir):
+    # 351 tags + fp16 weights + fp32 biases
+    assert os.path.getsize(os.path.join(model_dir, "x4.bin")) == 33424520
+
+
+def test_graph_interpreter_matches_pytorch(oracle_net, weights):
+    assert oracle_net.num_layers == 999 and oracle_net.num_convs == 351 and oracle_net.bin_encoding == 1
+    img = synth.make_image(1, 36, 28)
+    x = img.astype(np.float32).transpose(2, 0, 1) / 255.0
+    got = oracle_net.forward(x)
+    want = net_forward_np(weights, x)
+    assert got.shape == (3, 112, 144)
+    assert np.abs(got - want).max() < 2e-5  # fp32 summation order only
+    assert got.std() > 0.1  # the synthetic net is not degenerate
+
+
+def test_conv_records_follow_bin_order(oracle_net, weights):
+    for i in (0, 1, 5, 17, 345, 346, 350):
+        c = oracle_net.conv(i)
+        W, b = weights[i]
+        assert c["weight"].shape == W.shape
+        assert (c["weight"] == W).all() and (c["bias"] == b).all()
+        assert c["act"] == synth.conv_specs()[i][2]
+
+
+def test_raw_fp32_bin_encoding(tmp_path, weights, oracle_net):
+    d = tmp_path / "models-DF2K"
+    d.mkdir()
+    synth.write_param(str(d / "x4.param"))
+    synth.write_bin(str(d / "x4.bin"), weights, "fp32")
+    assert os.path.getsize(d / "x4.bin") == 66793352
+    n2 = oracle.OracleNet(str(d / "x4.param"), str(d / "x4.bin"))
+    assert n2.bin_encoding == 0
+    x = synth.make_image(2, 16, 12).astype(np.float32).transpose(2, 0, 1) / 255.0
+    assert (n2.forward(x) == oracle_net.forward(x)).all()
+
+
+def test_truncated_bin_is_rejected(tmp_path, model_dir):
+    data = open(os.path.join(model_dir, "x4.bin"), "rb").read()
+    p = tmp_path / "x4.bin"
+    p.write_bytes(data[:-7])
+    with pytest.raises(RuntimeError):
+        oracle.OracleNet(os.path.join(model_dir, "x4.param"), str(p))
+    p.write_bytes(data + b"\0\0\0\0")
+    with pytest.raises(RuntimeError):
+        oracle.OracleNet(os.path.join(model_dir, "x4.param"), str(p))
+
+
+# ---- an independent numpy statement of the tiling in realsr.cpp:525-838 ---------------------------
+def tiled_reference(weights, img, T, P=10, tta=False):
+    h, w, c = img.shape
+    out = np.zeros((h * 4, w * 4, 3), np.float32)
+    planar = img[:, :, :3].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+    for y0 in range(0, h, T):
+        for x0 in range(0, w, T):
+            y1, x1 = min(y0 + T, h), min(x0 + T, w)
+            # gather the halo'd window with reflect-101 at the image borders
+            ys = np.arange(y0 - P, y1 + P)
+            xs = np.arange(x0 - P, x1 + P)
+            ys = np.abs(ys); ys = (h - 1) - np.abs(ys - (h - 1))
+            xs = np.abs(xs); xs = (w - 1) - np.abs(xs - (w - 1))
+            tile = planar[:, ys][:, :, xs]
+            if not tta:
+                o = net_forward_np(weights, tile)
+            else:
+                acc = 0
+                for k in range(8):
+                    t = tile
+                    if k & 4: t = t.transpose(0, 2, 1)
+                    if k & 1: t = t[:, ::-1]
+                    if k & 2: t = t[:, :, ::-1]
+                    r = net_forward_np(weights, np.ascontiguousarray(t))
+                    if k & 2: r = r[:, :, ::-1]
+                    if k & 1: r = r[:, ::-1]
+                    if k & 4: r = r.transpose(0, 2, 1)
+                    acc = acc + r
+                o = acc / 8
+            o = o[:, 4 * P:o.shape[1] - 4 * P, 4 * P:o.shape[2] - 4 * P]
+            out[4 * y0:4 * y1, 4 * x0:4 * x1] = o.transpose(1, 2, 0)
+    return out
+
+
+@pytest.mark.parametrize("w,h,T,tta", [(41, 35, 32, False), (20, 45, 32, False), (26, 22, 16, True)])
+def test_process_matches_independent_tiling(oracle_net, weights, w, h, T, tta):
+    img = synth.make_image(11, w, h)
+    got, got32 = oracle_net.process(img, T, tta=tta, want_f32=True)
+    want32 = tiled_reference(weights, img, T, tta=tta)
+    assert np.abs(got32 - want32).max() < 5e-5
+    want = np.clip((want32 * 255.0 + 0.5).astype(np.int32), 0, 255)
+    d = np.abs(got.astype(int) - want)
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3  # only exact .5 ties may differ
+
+
+def test_tile_size_changes_the_result(oracle_net):
+    """Halo (10) << receptive field: results legitimately depend on -t."""
+    img = synth.make_image(12, 40, 40)
+    a = oracle_net.process(img, 32)
+    b = oracle_net.process(img, 64)
+    assert a.shape == b.shape == (160, 160, 3)
+    assert (a != b).any()
+
+
+def test_shader_restatements_agree_with_cpu_path():
+    """realsr_preproc.comp over a row band == crop + /255 + reflect border of process_cpu."""
+    img = synth.make_image(13, 45, 38)
+    h, w, _ = img.shape
+    T, P = 32, 10
+    planar = img.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+    for yi in range(2):
+        y0, y1 = max(yi * T - P, 0), min((yi + 1) * T + P, h)
+        band = img[y0:y1]
+        for xi in range(2):
+            twn = min((xi + 1) * T, w) - xi * T
+            thn = min((yi + 1) * T, h) - yi * T
+            top = oracle.preproc(band, twn + 2 * P, thn + 2 * P, P, P, xi * T, min(yi * T, P))
+            ys = np.arange(yi * T - P, yi * T + thn + P); ys = np.abs(ys); ys = (h - 1) - np.abs(ys - (h - 1))
+            xs = np.arange(xi * T - P, xi * T + twn + P); xs = np.abs(xs); xs = (w - 1) - np.abs(xs - (w - 1))
+            want = planar[:, ys][:, :, xs].astype(np.float16)
+            assert (top.view(np.uint16) == want.view(np.uint16)).all()
+            tt = oracle.preproc_tta(band, twn + 2 * P, thn + 2 * P, P, P, xi * T, min(yi * T, P))
+            assert (tt[0] == top).all()
+            assert (tt[1] == top[:, :, ::-1]).all() and (tt[2] == top[:, ::-1, ::-1]).all() and (tt[3] == top[:, ::-1]).all()
+            tr = top.transpose(0, 2, 1)
+            assert (tt[4] == tr).all() and (tt[5] == tr[:, :, ::-1]).all()
+            assert (tt[6] == tr[:, ::-1, ::-1]).all() and (tt[7] == tr[:, ::-1]).all()
+
+
+def test_postproc_restatement_store_rule():
+    bot = np.zeros((3, 8, 8), np.float16)
+    vals = [-0.3, 0.0, 0.00196, 0.5, 0.99803, 1.0, 1.7, 0.4980]
+    bot[0, 0, :8] = vals
+    out = np.full((8, 8, 3), 77, np.uint8)
+    oracle.postproc(bot, out, 0, 8, 0, 0)
+    want = [int(min(max(np.floor(np.float32(np.float16(v)) * np.float32(255) + np.float32(0.5)), 0), 255)) for v in vals]
+    assert out[0, :, 0].tolist() == want
+    assert out[0, 0, 0] == 0 and out[0, 6, 0] == 255
+
+
+def test_bicubic_is_ncnn_flavoured():
+    """Interior taps: Keys cubic A=-0.75 with half-pixel mapping == torch bicubic (align_corners=False);
+    borders: ncnn folds the out-of-range taps by re-weighting (Appendix A.5) instead of clamping."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    a = rng.random((9, 11)).astype(np.float32) * 255
+    o = oracle.bicubic(a, 36, 44)
+    t = F.interpolate(torch.from_numpy(a)[None, None], scale_factor=4, mode="bicubic", align_corners=False)[0, 0].numpy()
+    assert np.abs(o[8:-8, 8:-8] - t[8:-8, 8:-8]).max() < 1e-3
+    const = oracle.bicubic(np.full((4, 4), 9.0, np.float32), 16, 16)
+    assert np.allclose(const, 9.0, atol=1e-5)
+    # weights of every output pixel sum to 1 also at the re-weighted borders
+    ramp = oracle.bicubic(np.ones((5, 6), np.float32) * 3.0, 20, 24)
+    assert np.allclose(ramp, 3.0, atol=1e-5)
+
+
+def test_rgba_alpha_is_bicubic_of_the_cropped_tile(oracle_net):
+    img = synth.make_image(14, 20, 12, 4)
+    out = oracle_net.process(img, 16)
+    assert out.shape == (48, 80, 4)
+    # first tile: alpha = bicubic x4 of the 16x12 alpha block, +0.5, saturate
+    a = img[:12, :16, 3].astype(np.float32)
+    want = np.clip((oracle.bicubic(a, 48, 64) + 0.5).astype(np.int32), 0, 255)
+    assert (out[:, :64, 3] == want).all()

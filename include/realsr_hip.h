@@ -146,6 +146,10 @@ typedef struct rsr_profile
 int rsr_set_profiling(rsr_ctx* ctx, int enable);
 int rsr_get_profile(rsr_ctx* ctx, rsr_profile* out, int reset);
 
+/* Accumulated HIP-event time per convolution of x4.param (index = order in the file, 351 entries),
+ * over the profiled calls since the last reset. */
+int rsr_get_conv_times(rsr_ctx* ctx, double* ms, int n, int reset);
+
 /* Engine knobs (optional).  key/value: "max_workspace_mb" (tile batch memory budget),
  * "trunk_fp32" (1: residual trunk kept in fp32 [default], 0: fp16 storage like the reference's
  * Vulkan path). */

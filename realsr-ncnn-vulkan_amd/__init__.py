@@ -21,7 +21,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 EXPORTS = [
     "rsr_create", "rsr_destroy", "rsr_load", "rsr_set_params", "rsr_process", "rsr_process_device",
     "rsr_model_pack", "rsr_load_packed", "rsr_model_info", "rsr_preproc", "rsr_preproc_tta", "rsr_postproc",
-    "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile",
+    "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times",
     "rsr_set_option", "rsr_last_error", "rsr_version",
 ]
 
@@ -60,6 +60,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # When PyTorch shares the process (tests, bench: device tensors + torch.distributed), its bundled HIP
+    # runtime must be the one that is loaded first; loading /opt/rocm's copy first leaves torch without a GPU.
+    if os.environ.get("RSR_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or make -C realsr-ncnn-vulkan_amd/csrc)" % LIB_PATH)
@@ -84,6 +91,7 @@ def lib():
     L.rsr_conv3x3.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp]
     L.rsr_set_profiling.argtypes = [vp, ip]
     L.rsr_get_profile.argtypes = [vp, C.POINTER(Profile), ip]
+    L.rsr_get_conv_times.argtypes = [vp, C.POINTER(C.c_double), ip, ip]
     L.rsr_set_option.argtypes = [vp, cp, C.c_longlong]
     L.rsr_last_error.argtypes = [vp]
     L.rsr_last_error.restype = cp
@@ -244,6 +252,11 @@ class RealSR:
 
     def set_profiling(self, on):
         self._ck(self._L.rsr_set_profiling(self._h, int(bool(on))))
+
+    def get_conv_times(self, reset=True):
+        arr = (C.c_double * 351)()
+        self._ck(self._L.rsr_get_conv_times(self._h, arr, 351, int(bool(reset))))
+        return np.array(arr[:])
 
     def get_profile(self, reset=True):
         p = Profile()

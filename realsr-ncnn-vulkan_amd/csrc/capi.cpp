@@ -282,6 +282,15 @@ int rsr_get_profile(rsr_ctx* ctx, rsr_profile* out, int reset)
     return RSR_OK;
 }
 
+int rsr_get_conv_times(rsr_ctx* ctx, double* ms, int n, int reset)
+{
+    if (!ctx || !ms || n < 0) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    for (int i = 0; i < n && i < kNumConvs; i++) ms[i] = ctx->e.conv_ms_by_index[i];
+    if (reset) std::memset(ctx->e.conv_ms_by_index, 0, sizeof ctx->e.conv_ms_by_index);
+    return RSR_OK;
+}
+
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
 {
     if (!ctx || !key) return RSR_E_ARG;

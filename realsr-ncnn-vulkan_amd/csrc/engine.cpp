@@ -297,13 +297,13 @@ void Engine::mark_begin(hipStream_t st)
     if (hipEvent_t ev = next_event(*this)) (void)hipEventRecord(ev, st);
 }
 
-void Engine::mark(int cls, double flops, double bytes, hipStream_t st)
+void Engine::mark(int cls, double flops, double bytes, hipStream_t st, int conv_index)
 {
     if (!profiling || ev_used == 0) return;
     if (hipEvent_t ev = next_event(*this))
     {
         (void)hipEventRecord(ev, st);
-        segs.push_back(Seg{cls, flops, bytes});
+        segs.push_back(Seg{cls, flops, bytes, conv_index});
     }
 }
 
@@ -316,7 +316,13 @@ void Engine::collect_profile(hipStream_t st)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) != hipSuccess) continue;
         const Seg& s = segs[i];
-        if (s.cls == 1) { prof.conv_ms += ms; prof.conv_flops += s.flops; prof.conv_launches++; }
+        if (s.cls == 1)
+        {
+            prof.conv_ms += ms;
+            prof.conv_flops += s.flops;
+            prof.conv_launches++;
+            if (s.conv_index >= 0 && s.conv_index < kNumConvs) conv_ms_by_index[s.conv_index] += ms;
+        }
         else if (s.cls == 0) { prof.pre_ms += ms; prof.pre_bytes += s.bytes; }
         else if (s.cls == 2) { prof.post_ms += ms; prof.post_bytes += s.bytes; }
     }
@@ -365,7 +371,7 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
     auto go = [&](ConvArgs& a) {
         const PackedConv& c = convs[size_t(ci)];
         launch_conv(a, int(c.nt), use_dma, st);
-        mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out], 0, st);
+        mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out], 0, st, ci);
         ci++;
     };
     const PlaneSrc fea = PS(b_fea, 2, pb16, 0);

@@ -81,7 +81,9 @@ struct Engine
     {
         int cls; // 0 pre, 1 conv, 2 post
         double flops, bytes;
+        int conv_index;
     };
+    double conv_ms_by_index[kNumConvs] = {0};
     std::vector<Seg> segs;
     size_t ev_used = 0;
     rsr_profile prof{};
@@ -102,7 +104,7 @@ struct Engine
     int ensure_workspace(int nslots, long long cap_px);
     void run_network(const Plan::Batch& b, hipStream_t st);
     void mark_begin(hipStream_t st);
-    void mark(int cls, double flops, double bytes, hipStream_t st);
+    void mark(int cls, double flops, double bytes, hipStream_t st, int conv_index = -1);
     void collect_profile(hipStream_t st);
     void free_plan();
     int fail(int code, const std::string& msg);

@@ -130,41 +130,56 @@ def sec_e2e(net):
         sr.close()
 
 
+def layer_table(ct, npx):
+    """ct: per-conv ms (351) for ONE frame; npx: padded LR px per frame."""
+    specs = synth.conv_specs()
+    groups = {}
+    for i, (cin, cout, act) in enumerate(specs):
+        lvl = 0 if i <= 346 else (1 if i == 347 else 2)
+        name = "%3d->%-2d @%dx" % (cin, cout, 1 << lvl)
+        g = groups.setdefault(name, [0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += ct[i]
+        g[2] += 2.0 * 9 * cin * cout * npx * (4 ** lvl)
+    for name, (n, ms, fl) in groups.items():
+        print("      %s x%-3d %8.3f ms  %7.1f TFLOP/s (%4.1f%%)  avg %7.1f us" % (name, n, ms, fl / ms / 1e9, fl / ms / 1e9 / 25, ms / n * 1e3))
+
+
 def sec_perf():
-    print("== timing: 1920x1080 T=200 (C2), host API and device API")
+    print("== timing: 1920x1080 T=200 (C2), device API")
     import torch
     pp, bp = os.path.join(MODELS, "models-DF2K", "x4.param"), os.path.join(MODELS, "models-DF2K", "x4.bin")
     sr = R.RealSR(0)
     sr.load(pp, bp)
     sr.tilesize = 200
     w, h = 1920, 1080
+    npx = 2544000
     img = synth.make_image(3, w, h)
     d_in = torch.from_numpy(img).cuda()
     d_out = torch.empty((h * 4, w * 4, 3), dtype=torch.uint8, device="cuda")
-    for dma in (1, 0):
-        sr.set_option("use_dma", dma)
-        for tf in (1, 0):
-            sr.set_option("trunk_fp32", tf)
-            sr.process_device(d_in.data_ptr(), w, h, 3, d_out.data_ptr())  # warmup (allocs)
-            torch.cuda.synchronize()
-            t = time.time()
-            n = 3
-            for _ in range(n):
-                sr.process_device(d_in.data_ptr(), w, h, 3, d_out.data_ptr())
-            torch.cuda.synchronize()
-            dt = (time.time() - t) / n
-            sr.set_profiling(True)
+    variants = os.environ.get("RSR_PERF_VARIANTS", "dma=1,trunk_fp32=1;dma=1,trunk_fp32=0").split(";")
+    for var in variants:
+        opts = dict(kv.split("=") for kv in var.split(",") if kv)
+        for k, v in opts.items():
+            sr.set_option({"dma": "use_dma"}.get(k, k), int(v))
+        sr.process_device(d_in.data_ptr(), w, h, 3, d_out.data_ptr())  # warmup (allocs)
+        torch.cuda.synchronize()
+        t = time.time()
+        n = 3
+        for _ in range(n):
             sr.process_device(d_in.data_ptr(), w, h, 3, d_out.data_ptr())
-            p = sr.get_profile()
-            sr.set_profiling(False)
-            print("  dma=%d trunk_fp32=%d: %.1f ms/frame = %.1f Mpix/s out; conv %.1f ms, %.1f TFLOP -> %.1f TFLOP/s (%.1f%% of 2.5 PF); pre %.3f ms post %.3f ms" % (
-                dma, tf, dt * 1e3, 33.1776 / dt, p["conv_ms"], p["conv_flops"] / 1e12, p["conv_flops"] / p["conv_ms"] / 1e9,
-                p["conv_flops"] / p["conv_ms"] / 1e9 / 2500 * 100, p["pre_ms"], p["post_ms"]), flush=True)
-    sr.set_option("use_dma", 1)
-    sr.set_option("trunk_fp32", 1)
-    t = time.time()
-    out = sr.process(img)
-    print("  host API (H2D + D2H incl.): %.1f ms" % ((time.time() - t) * 1e3), "checksum", int(out.astype(np.uint64).sum()))
+        torch.cuda.synchronize()
+        dt = (time.time() - t) / n
+        sr.set_profiling(True)
+        sr.get_conv_times(reset=True)
+        sr.process_device(d_in.data_ptr(), w, h, 3, d_out.data_ptr())
+        p = sr.get_profile()
+        ct = sr.get_conv_times()
+        sr.set_profiling(False)
+        print("  %s: %.1f ms/frame = %.1f Mpix/s out; conv %.1f ms, %.1f TFLOP -> %.1f TFLOP/s (%.1f%% of 2.5 PF); pre %.3f ms post %.3f ms" % (
+            var, dt * 1e3, 33.1776 / dt, p["conv_ms"], p["conv_flops"] / 1e12, p["conv_flops"] / p["conv_ms"] / 1e9,
+            p["conv_flops"] / p["conv_ms"] / 1e9 / 2500 * 100, p["pre_ms"], p["post_ms"]), flush=True)
+        layer_table(ct, npx)
     sr.close()
 
 

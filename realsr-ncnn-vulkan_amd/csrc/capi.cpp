@@ -154,12 +154,12 @@ static int preproc_common(rsr_ctx* ctx, const uint8_t* band, int w, int h, int c
     for (int i = 0; i < ntop; i++)
     {
         CK(hipMalloc(&d_top[i], ntile));
-        CK(hipMemset(d_top[i], 0, ntile));
+        CK(hipMemsetAsync(d_top[i], 0, ntile, st)); // same stream as the kernel: the null stream does not order with it
     }
     if (nalpha)
     {
         CK(hipMalloc(&d_alpha, nalpha));
-        CK(hipMemset(d_alpha, 0, nalpha));
+        CK(hipMemsetAsync(d_alpha, 0, nalpha, st));
     }
     launch_preproc_shader(d_in, w, h, channels, d_top, ntop, outw, outh, outw * outh, pad_top, pad_left, crop_x, crop_y, d_alpha,
                           alphaw, alphah, 0, st);
@@ -306,6 +306,18 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         ctx->e.trunk_fp32 = value != 0;
     else if (k == "use_dma")
         ctx->e.use_dma = value != 0;
+    else if (k == "kernel")
+    {
+        if (value != 1 && value != 2) return ctx->e.fail(RSR_E_ARG, "kernel must be 1 or 2");
+        ctx->e.kernel_version = int(value);
+    }
+    else if (k == "dbg")
+        ctx->e.dbg = int(value);
+    else if (k == "num_cu")
+    {
+        if (value < 8 || value > 1024) return ctx->e.fail(RSR_E_ARG, "num_cu out of range");
+        ctx->e.num_cu = int(value);
+    }
     else
         return ctx->e.fail(RSR_E_ARG, "unknown option " + k);
     return RSR_OK;

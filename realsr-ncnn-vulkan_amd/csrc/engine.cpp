@@ -45,10 +45,12 @@ int Engine::init(int gpuid, int tta_mode)
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RSR_E_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&zeros.p, 256));
     zeros.bytes = 256;
-    HIP_TRY(hipMemset(zeros.p, 0, 256));
+    HIP_TRY(hipMemsetAsync(zeros.p, 0, 256, stream)); // on OUR stream: it is non-blocking, the null stream does not order with it
+    HIP_TRY(hipStreamSynchronize(stream));
     return RSR_OK;
 }
 
@@ -147,7 +149,7 @@ static void make_items(Plan::Batch& b)
             const int H = b.dims[size_t(s)].h << lvl, W = b.dims[size_t(s)].w << lvl;
             b.px[lvl] += double(H) * W;
             for (int y0 = 0; y0 < H; y0 += kBlkH)
-                for (int x0 = 0; x0 < W; x0 += kBlkW) b.items[lvl].push_back(WorkItem{s, y0, x0, 0});
+                for (int x0 = 0; x0 < W; x0 += kBlkW) b.items[lvl].push_back(WorkItem{s, y0, x0, H, W, 0, 0, 0});
         }
     }
 }
@@ -365,12 +367,14 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         a.nitems = int(b.items[lvl_out].size());
         a.dims = b.d_dims;
         a.zeros = zeros.p;
+        a.dbg = dbg;
         a.s1 = a.s2 = 1.f;
         return a;
     };
     auto go = [&](ConvArgs& a) {
         const PackedConv& c = convs[size_t(ci)];
-        launch_conv(a, int(c.nt), use_dma, st);
+        if (kernel_version == 2) launch_conv_pipe(a, int(c.nt), num_cu, st);
+        else launch_conv(a, int(c.nt), use_dma, st);
         mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out], 0, st, ci);
         ci++;
     };
@@ -600,7 +604,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     DevBuf d_w, d_in, d_out, d_tab;
     std::vector<WorkItem> items;
     for (int y0 = 0; y0 < H; y0 += kBlkH)
-        for (int x0 = 0; x0 < W; x0 += kBlkW) items.push_back(WorkItem{0, y0, x0, 0});
+        for (int x0 = 0; x0 < W; x0 += kBlkW) items.push_back(WorkItem{0, y0, x0, H, W, 0, 0, 0});
     const TileDim td{h, w};
     auto cleanup = [&]() {
         for (DevBuf* b : {&d_w, &d_in, &d_out, &d_tab})
@@ -614,7 +618,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     }
     (void)hipMemcpy(d_w.p, pk.data(), pk.size(), hipMemcpyHostToDevice);
     (void)hipMemcpy(d_in.p, hin.data(), hin.size() * 2, hipMemcpyHostToDevice);
-    (void)hipMemset(d_out.p, 0, hout.size() * 2);
+    (void)hipMemsetAsync(d_out.p, 0, hout.size() * 2, stream);
     (void)hipMemcpy(d_tab.p, &td, sizeof td, hipMemcpyHostToDevice);
     (void)hipMemcpy(static_cast<char*>(d_tab.p) + 256, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice);
     ConvArgs a;
@@ -632,7 +636,8 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     a.nitems = int(items.size());
     a.dims = static_cast<const TileDim*>(d_tab.p);
     a.zeros = zeros.p;
-    launch_conv(a, nt, use_dma, stream);
+    if (kernel_version == 2) launch_conv_pipe(a, nt, num_cu, stream);
+    else launch_conv(a, nt, use_dma, stream);
     hipError_t he = hipStreamSynchronize(stream);
     if (he == hipSuccess) he = hipGetLastError();
     if (he == hipSuccess) he = hipMemcpy(hout.data(), d_out.p, hout.size() * 2, hipMemcpyDeviceToHost);

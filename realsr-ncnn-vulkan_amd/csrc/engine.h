@@ -54,6 +54,9 @@ struct Engine
     bool loaded = false;
     bool trunk_fp32 = true;
     bool use_dma = true;
+    int kernel_version = 2; // 2: conv3x3_pipe (persistent, wave-specialised), 1: conv3x3_mfma
+    int num_cu = 256;
+    int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
     long long max_workspace_mb = 65536;
     hipStream_t stream = nullptr;
 

@@ -20,11 +20,13 @@ constexpr int kBlkH = 16, kBlkW = 32;          // output block of one workgroup
 constexpr int kPatchH = kBlkH + 2, kPatchW = kBlkW + 2;
 constexpr int kPatchPx = kPatchH * kPatchW;     // 612
 constexpr int kPatchBytes = kPatchPx * 64;      // 39168
-constexpr int kPatchLds = 40960;                // LDS bytes reserved for the patch (10 x 256 x 16: whole DMA passes)
+constexpr int kPatchLds = 39936;                // LDS bytes reserved for the patch: 39 wave-sized (1 KiB) LDS-DMA pieces
 
-struct WorkItem
+struct WorkItem // 32 bytes: one aligned 2 x 16-byte fetch gives a workgroup everything about its block
 {
-    int slot, y0, x0, pad;
+    int slot, y0, x0; // tile slot and block origin at this table's resolution level
+    int H, W;         // dims of the slot's tile at this level (output dims of the conv)
+    int pad0, pad1, pad2;
 };
 
 struct TileDim
@@ -66,9 +68,11 @@ struct ConvArgs
     int nitems;
     const TileDim* dims;
     const void* zeros; // >= 16 zero bytes in device memory (LDS-DMA source for out-of-image pixels)
+    int dbg;           // ablation switches for profiling (conv3x3_pipe): 1 skip DMA, 2 skip MFMA, 4 skip epilogue, 8 coalesced epilogue
 };
 
 void launch_conv(const ConvArgs& a, int nt, bool dma, hipStream_t st);
+void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st); // persistent wave-specialised variant
 
 // ---- pre / post ------------------------------------------------------------------------------
 struct BaseTile

@@ -52,6 +52,141 @@ __device__ __forceinline__ const char* plane_ptr(const PlaneSrc& s, int slot, in
     return static_cast<const char*>(s.base) + (long long)slot * s.slot_stride + (long long)plane * s.plane_stride;
 }
 
+// Fused epilogue (bias, LeakyReLU, residual axpy stages, fp16/fp32/planar stores) for one output block.
+// acc[rr] = rows 4*wrow + rr of the block, output channels nt*32 .. nt*32+31.
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[4], const f32x4 (&bq)[4], int nt, int slot, int y0, int x0,
+                                              int H, int W, int wrow, int l32, int hi)
+{
+    const int x = x0 + l32;
+    {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+        {
+            const int y = y0 + wrow * 4 + rr;
+            if (y >= H || x >= W) continue;
+            const long long pix = (long long)y * W + x;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                const int c0 = q * 8 + hi * 4; // channel within the 32-plane
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    float t = acc[rr][q * 4 + e] + bq[q][e];
+                    if (a.lrelu) t = t > 0.f ? t : t * 0.2f;
+                    v[e] = t;
+                }
+                if (a.res1_kind == 2)
+                {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(plane_ptr(a.res1, slot, nt) + (pix * 32 + c0) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s1 + r[e];
+                }
+                else if (a.res1_kind == 1)
+                {
+                    const half4 r = *reinterpret_cast<const half4*>(plane_ptr(a.res1, slot, nt) + (pix * 32 + c0) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s1 + (float)r[e];
+                }
+                if (a.res2_kind == 2)
+                {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(plane_ptr(a.res2, slot, nt) + (pix * 32 + c0) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s2 + r[e];
+                }
+                else if (a.res2_kind == 1)
+                {
+                    const half4 r = *reinterpret_cast<const half4*>(plane_ptr(a.res2, slot, nt) + (pix * 32 + c0) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s2 + (float)r[e];
+                }
+                if (a.out16.base)
+                {
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
+                    *reinterpret_cast<half4*>(const_cast<char*>(plane_ptr(a.out16, slot, nt)) + (pix * 32 + c0) * 2) = o;
+                }
+                if (a.out32a.base)
+                    *reinterpret_cast<f32x4*>(const_cast<char*>(plane_ptr(a.out32a, slot, nt)) + (pix * 32 + c0) * 4) = v;
+                if (a.out32b.base)
+                    *reinterpret_cast<f32x4*>(const_cast<char*>(plane_ptr(a.out32b, slot, nt)) + (pix * 32 + c0) * 4) = v;
+                if (a.out_planar3 && nt == 0 && q == 0 && hi == 0)
+                {
+                    _Float16* o = reinterpret_cast<_Float16*>(static_cast<char*>(a.out_planar3) + (long long)slot * a.planar3_slot_stride);
+                    const long long hw = (long long)H * W;
+                    o[pix] = (_Float16)v[0];
+                    o[hw + pix] = (_Float16)v[1];
+                    o[2 * hw + pix] = (_Float16)v[2];
+                }
+            }
+        }
+    }
+}
+
+// Specialised, branch-free epilogues of conv3x3_pipe (channel-major accumulators: lane (p = lane&31, hi) holds the
+// channels q*8 + hi*4 .. +3, q = 0..3, of pixel p of each of the wave's 4 rows).  The generic conv_epilogue above
+// decides everything per element with wave-uniform branches on ConvArgs fields; measured on MI355X that scalar
+// control flow made the epilogue the largest single cost of a launch (~4 us per work item, ~16 us for the
+// residual variant).  Here the variant is a template parameter, interior blocks skip all bounds tests, and the
+// residual planes are fetched for the whole block before the first use.
+//   EPI 1: v = act(acc + b)                       -> fp16 plane          (dense-block convs 1-4, up/HR convs)
+//   EPI 2: v = (acc + b)*s1 + r1 [, v = v*s2 + r2] -> fp16 plane          (dense-block conv 5, trunk conv; fp16 residuals)
+template <int EPI, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_t(const ConvArgs& a, f32x16 (&acc)[4], const f32x4 (&bq)[4], int nt, int slot, int y0,
+                                                int x0, int H, int W, int wrow, int l32, int hi)
+{
+    const int x = x0 + l32;
+    const bool xin = !CHECK || x < W;
+    char* op = const_cast<char*>(plane_ptr(a.out16, slot, nt)) + hi * 8;
+    const float slope = a.lrelu ? 0.2f : 1.f;
+    long long off[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) off[rr] = ((long long)(y0 + wrow * 4 + rr) * W + x) * 64;
+    half4 r1[4][4], r2[4][4];
+    const bool has2 = (EPI == 2) && a.res2_kind == 1;
+    if (EPI == 2)
+    {
+        const char* r1p = plane_ptr(a.res1, slot, nt) + hi * 8;
+        const char* r2p = has2 ? plane_ptr(a.res2, slot, nt) + hi * 8 : r1p;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+        {
+            const bool ok = xin && (!CHECK || y0 + wrow * 4 + rr < H);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                r1[rr][q] = ok ? *reinterpret_cast<const half4*>(r1p + off[rr] + q * 16) : half4{0, 0, 0, 0};
+                if (has2) r2[rr][q] = ok ? *reinterpret_cast<const half4*>(r2p + off[rr] + q * 16) : half4{0, 0, 0, 0};
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+    {
+        const bool ok = xin && (!CHECK || y0 + wrow * 4 + rr < H);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                float v = acc[rr][q * 4 + e] + bq[q][e];
+                if (EPI == 1) v = fmaxf(v, v * slope); // LeakyReLU(0.2) or identity, branch-free
+                if (EPI == 2)
+                {
+                    v = v * a.s1 + (float)r1[rr][q][e];
+                    if (has2) v = v * a.s2 + (float)r2[rr][q][e];
+                }
+                o[e] = (_Float16)v;
+            }
+            if (ok) *reinterpret_cast<half4*>(op + off[rr] + q * 16) = o;
+        }
+    }
+}
+
 // DMA = true: both LDS images are filled by LDS-DMA (global_load_lds_dwordx4: per-lane global source,
 // wave-uniform LDS base + lane*16 destination), so staging costs no VGPRs and no ds_write; the XOR
 // swizzle is applied on the SOURCE address (LDS item i receives logical slot (i&3)^((i>>4)&3) of
@@ -77,9 +212,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma(const ConvArgs a)
     if (item >= a.nitems) return;
     const WorkItem it = a.items[item];
     const int slot = it.slot, y0 = it.y0, x0 = it.x0;
-    const TileDim td = a.dims[slot];
-    const int H = td.h << a.lvl_out, W = td.w << a.lvl_out; // output dims
-    const int Wi = td.w << a.lvl_in;                        // input row pitch in pixels
+    const int H = it.H, W = it.W;        // output dims
+    const int Wi = UPS ? (W >> 1) : W;   // input row pitch in pixels
 
     // ---- staging addresses (chunk invariant) ----
     int srcoff[kPatchIters]; // byte offset inside a plane, -1 = zero fill
@@ -129,8 +263,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma(const ConvArgs a)
             for (int i = 0; i < kPatchIters; i++)
             {
                 const char* src = srcoff[i] >= 0 ? plane + srcoff[i] : zp;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(smem + (i * kThreads + wave * 64) * 16), 16, 0, 0);
+                if ((i * kThreads + wave * 64) * 16 < kPatchLds) // wave-uniform: the 40th 1-KiB piece does not exist
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(smem + (i * kThreads + wave * 64) * 16), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < WITERS; i++)
@@ -277,6 +412,264 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma(const ConvArgs a)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3_pipe: the same arithmetic as conv3x3_mfma, restructured for latency:
+//   * persistent: gridDim = #CUs; each workgroup walks a strided list of work items, so the chunk
+//     stream never drains between items (a 64->32 conv is only 2 chunks long),
+//   * wave-specialised: waves 0-3 only ds_read + MFMA, waves 4-7 only issue LDS-DMA (they share the
+//     SIMDs pairwise, so DMA issue slots never sit between two MFMAs of the same wave),
+//   * double-buffered LDS: the loaders fill stage s+1 while stage s is being multiplied; one
+//     barrier per stage,
+//   * MFMA operand fragments are software-pipelined one (dx, 16-channel) step ahead.
+// ---------------------------------------------------------------------------------------------
+template <int NT, bool UPS, int EPI>
+__global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const ConvArgs a)
+{
+    // waves [0, 4*NT): compute -- wave w owns rows 4*(w&3).. of the block and output channels 32*(w>>2)..;
+    // waves [4*NT, 4*NT+4): loaders.  NT=1: 8 waves (2 per SIMD), NT=2: 12 waves (3 per SIMD, <= 168 VGPRs).
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCW = 4 * NT;
+    constexpr int WROWS = 9 * NT * 32;
+    constexpr int WITEMS = WROWS * 4;
+    constexpr int WPASS = (WITEMS + 255) / 256;
+    constexpr int STAGE = kPatchLds + WROWS * 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nplanes = a.n0 + a.n1;
+
+    // work items of this workgroup: XCD x gets the contiguous range [x*per, (x+1)*per); its nj workgroups stride it
+    const int per = (a.nitems + 7) >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    const int first = xcd * per + j;
+    const int end = min((xcd + 1) * per, a.nitems);
+    const int nmine = first < end ? (end - first + nj - 1) / nj : 0;
+    if (nmine == 0) return;
+    const int S = nmine * nplanes;
+
+    if (wave >= NCW)
+    {
+        // ================= loader waves =================
+        const int lw = wave - NCW, ltid = lw * 64 + lane;
+        const char* zp = static_cast<const char*>(a.zeros);
+        const char* wbase = static_cast<const char*>(a.wpk);
+        int t = 0;
+        WorkItem nxt = a.items[first];
+        for (int r = 0; r < nmine; r++)
+        {
+            // the descriptor of item r was fetched one item ago; item r+1's is requested now and lands while
+            // this item's stages stream (no dependent global load sits in front of a DMA issue)
+            const WorkItem it = nxt;
+            if (r + 1 < nmine) nxt = a.items[first + (r + 1) * nj];
+            const int H = it.H, W = it.W, Wi = UPS ? (W >> 1) : W;
+            int srcoff[kPatchIters];
+#pragma unroll
+            for (int i = 0; i < kPatchIters; i++)
+            {
+                const int jj = ltid + i * 256;
+                const int px = jj >> 2, sl = jj & 3;
+                const int rr = px / kPatchW, cc = px - rr * kPatchW;
+                const int gy = it.y0 - 1 + rr, gx = it.x0 - 1 + cc;
+                const bool ok = (jj < kPatchItems) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const int sy = UPS ? (gy >> 1) : gy, sx = UPS ? (gx >> 1) : gx;
+                // LDS item jj receives logical 16-B slot sl ^ ((column >> 2) & 3) of its pixel (column swizzle)
+                srcoff[i] = ok ? ((sy * Wi + sx) * 64 + ((sl ^ ((cc >> 2) & 3)) << 4)) : -1;
+            }
+            for (int ck = 0; ck < nplanes; ck++, t++)
+            {
+                if (t > 0)
+                {
+                    // Raw barrier (not __syncthreads): drain OUR LDS-DMA explicitly (hipcc does not carry it across
+                    // this loop's back edge), then B_{t-1} publishes stage t-1 to the compute waves and tells us
+                    // that buffer t&1 is free.
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                char* buf = smem + (t & 1) * STAGE;
+                const char* plane = (ck < a.n0) ? plane_ptr(a.src0, it.slot, ck) : plane_ptr(a.src1, it.slot, ck - a.n0);
+                const char* wsrc = wbase + (long long)ck * (WROWS * 64);
+#pragma unroll
+                for (int i = 0; i < kPatchIters; i++)
+                {
+                    const char* src = srcoff[i] >= 0 ? plane + srcoff[i] : zp;
+                    if ((i * 256 + lw * 64) * 16 < kPatchLds && !(a.dbg & 1)) // wave-uniform: the 40th 1-KiB piece does not exist
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(buf + (i * 256 + lw * 64) * 16), 16, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < WPASS; i++)
+                {
+                    const int jw = i * 256 + lw * 64;
+                    if (jw < WITEMS && !(a.dbg & 1))
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (jw + lane) * 16),
+                                                         (__attribute__((address_space(3))) void*)(buf + kPatchLds + jw * 16), 16, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // barrier B_{S-1}
+        return;
+    }
+
+    // ================= compute waves =================
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int wrow = wave & 3, ntw = wave >> 2;
+    // LDS byte offsets (stage relative).  X: patch pixel (row, col) lives at (row*34 + col)*64 with its four 16-B
+    // slots XOR-swizzled by (col>>2)&3 (a 16-lane ds_read_b128 group covers 16 consecutive columns of one row:
+    // col&3 and (col>>2)&3 enumerate all 16 bank groups -> conflict-free for every tap shift).  The swizzle depends
+    // on the column only, so one VGPR per dx + immediate row offsets address all 18 fragments; cb flips bit 5.
+    // W: row = tap*NT*32 + nt*32 + l32 -> its swizzle ((row>>2)&3) depends on l32 only.
+    int xcol[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; dx++)
+    {
+        const int c = l32 + dx;
+        xcol[dx] = wrow * 4 * kPatchW * 64 + c * 64 + ((hi ^ ((c >> 2) & 3)) << 4);
+    }
+    const int woff = kPatchLds + (ntw * 32 + l32) * 64 + ((hi ^ ((l32 >> 2) & 3)) << 4);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[r][e] = 0.f;
+
+    // bias: copied to LDS once per launch (behind the two stage buffers); every epilogue re-reads its 16 values
+    // with 4 ds_read_b128 instead of pinning 16 VGPRs or paying a global-load latency per item
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE);
+    if (tid < NT * 32) bias_lds[tid] = a.bias[tid];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the ds_write has landed before this wave's first barrier
+
+    int r = 0, ck = 0;
+    WorkItem it = a.items[first];
+    WorkItem nxt = a.items[first + (nmine > 1 ? nj : 0)];
+    for (int s = 0; s < S; s++)
+    {
+        // Raw s_barrier, NOT __syncthreads(): the fence in __syncthreads() makes the wave wait (vmcnt(0)) for the
+        // acknowledgement of the previous item's epilogue stores -- measured ~5 us of dead time per work item.
+        // All this barrier must order is LDS: the DMA writes of stage s (drained by the loaders before they
+        // arrive) against our ds_reads below, and our reads of stage s-1 (consumed by MFMAs already) against
+        // the loaders' next fill.
+        asm volatile("s_barrier" ::: "memory"); // barrier B_s: stage s is in LDS
+        const char* buf = smem + (s & 1) * STAGE;
+        if (!(a.dbg & 2))
+        {
+        half8 X0[6], X1[6], W0[3], W1[3];
+#define RSR_LOAD_STEP(X, Wf, T)                                                                                     \
+    {                                                                                                                \
+        constexpr int dx_ = (T) >> 1, cb_ = (T)&1;                                                                   \
+        _Pragma("unroll") for (int rr = 0; rr < 6; rr++)                                                             \
+            X[rr] = *reinterpret_cast<const half8*>(buf + ((xcol[dx_] ^ (cb_ << 5)) + rr * (kPatchW * 64)));         \
+        _Pragma("unroll") for (int dy = 0; dy < 3; dy++)                                                             \
+            Wf[dy] = *reinterpret_cast<const half8*>(buf + ((woff ^ (cb_ << 5)) + (dy * 3 + dx_) * (NT * 32 * 64))); \
+    }
+#define RSR_MFMA_STEP(X, Wf)                                                                                         \
+    {                                                                                                                \
+        _Pragma("unroll") for (int dy = 0; dy < 3; dy++) _Pragma("unroll") for (int rr = 0; rr < 4; rr++)            \
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[dy], X[rr + dy], acc[rr], 0, 0, 0);                  \
+    }
+        RSR_LOAD_STEP(X0, W0, 0)
+        RSR_LOAD_STEP(X1, W1, 1)
+        RSR_MFMA_STEP(X0, W0)
+        RSR_LOAD_STEP(X0, W0, 2)
+        RSR_MFMA_STEP(X1, W1)
+        RSR_LOAD_STEP(X1, W1, 3)
+        RSR_MFMA_STEP(X0, W0)
+        RSR_LOAD_STEP(X0, W0, 4)
+        RSR_MFMA_STEP(X1, W1)
+        RSR_LOAD_STEP(X1, W1, 5)
+        RSR_MFMA_STEP(X0, W0)
+        RSR_MFMA_STEP(X1, W1)
+#undef RSR_LOAD_STEP
+#undef RSR_MFMA_STEP
+        // Pin the issue order (hipcc otherwise sinks every ds_read next to its MFMA with lgkmcnt(0) in
+        // front): fragments of steps 0,1 first, then each step's 12 MFMAs interleaved 1:1 with the 9
+        // ds_reads of the step two ahead.  Masks: 0x8 MFMA, 0x100 DS read.
+        __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+        {
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+            {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
+        }
+        if (++ck == nplanes)
+        {
+            if (!(a.dbg & 4))
+            {
+                f32x4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(bias_lds + ntw * 32 + q * 8 + hi * 4);
+                if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+                else if (it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W)
+                    conv_epilogue_t<EPI, false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+                else
+                    conv_epilogue_t<EPI, true>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+            }
+            ck = 0;
+            r++;
+            it = nxt;
+            if (r + 1 < nmine) nxt = a.items[first + (r + 1) * nj];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[rr][e] = 0.f;
+        }
+    }
+}
+
+template <int NT, bool UPS, int EPI>
+static void launch_conv_pipe_t(const ConvArgs& a, int ncu, hipStream_t st)
+{
+    const size_t lds = 2 * (size_t(kPatchLds) + size_t(9 * NT * 32 * 64)) + 256; // two stages + bias
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe<NT, UPS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        attr_set = true;
+    }
+    int grid = ncu & ~7; // multiple of 8 (XCD mapping)
+    const int per = (a.nitems + 7) / 8;
+    if (per * 8 < grid) grid = per * 8;
+    hipLaunchKernelGGL((conv3x3_pipe<NT, UPS, EPI>), dim3(grid), dim3((4 * NT + 4) * 64), lds, st, a);
+}
+
+void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st)
+{
+    if (a.nitems <= 0) return;
+    const bool ups = a.lvl_out != a.lvl_in;
+    // epilogue variant: fp16 plane out only -> 1 (no residual) / 2 (fp16 residuals); anything else -> generic
+    int epi = 0;
+    if (a.out16.base && !a.out32a.base && !a.out32b.base && !a.out_planar3 && !(a.dbg & 16))
+    {
+        if (a.res1_kind == 0 && a.res2_kind == 0) epi = 1;
+        else if (a.res1_kind == 1 && (a.res2_kind == 0 || a.res2_kind == 1)) epi = 2;
+    }
+#define RSR_PIPE(NT_, UPS_)                                                   \
+    do                                                                        \
+    {                                                                         \
+        if (epi == 1) launch_conv_pipe_t<NT_, UPS_, 1>(a, ncu, st);           \
+        else if (epi == 2) launch_conv_pipe_t<NT_, UPS_, 2>(a, ncu, st);      \
+        else launch_conv_pipe_t<NT_, UPS_, 0>(a, ncu, st);                    \
+    } while (0)
+    if (nt == 1)
+    {
+        if (ups) RSR_PIPE(1, true);
+        else RSR_PIPE(1, false);
+    }
+    else
+    {
+        if (ups) RSR_PIPE(2, true);
+        else RSR_PIPE(2, false);
+    }
+#undef RSR_PIPE
 }
 
 template <int NT, bool UPS, bool DMA>

@@ -34,8 +34,9 @@ def sec_conv(sr):
     rng = np.random.default_rng(0)
     cases = [(64, 32, 20, 40, False), (96, 32, 17, 33, False), (192, 64, 16, 32, False), (3, 64, 9, 70, False),
              (64, 3, 33, 31, False), (64, 64, 10, 21, True), (160, 32, 48, 64, False)]
-    for dma in (1, 0):
-        sr.set_option("use_dma", dma)
+    for dma in (2, 1):
+        sr.set_option("kernel", 2 if dma == 2 else 1)
+        sr.set_option("use_dma", 1)
         for cin, cout, h, w, ups in cases:
             x = rng.standard_normal((cin, h, w)).astype(np.float16)
             wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float16).astype(np.float32)
@@ -46,14 +47,14 @@ def sec_conv(sr):
                     xr = xr.repeat(2, axis=1).repeat(2, axis=2)
                 ref = oracle.conv3x3(xr, wt, b, 2 if lrelu else 0, 0.2)
                 got = sr.conv3x3(x, wt, b, lrelu=lrelu, upsample2x=ups).astype(np.float32)
-                m = stats("dma=%d %d->%d %dx%d ups=%d lrelu=%d" % (dma, cin, cout, h, w, ups, lrelu), got, ref)
+                m = stats("kern=%d %d->%d %dx%d ups=%d lrelu=%d" % (dma, cin, cout, h, w, ups, lrelu), got, ref)
                 if m > 0.05:
                     # help localise a layout bug
                     print("    first rows got:", got[0, 0, :6], " ref:", ref[0, 0, :6])
                     print("    per-channel max err (first 8):", np.abs(got - ref).reshape(cout, -1).max(1)[:8])
                     print("    per-row max err (first 8):", np.abs(got - ref).max(axis=(0, 2))[:8])
                     print("    per-col max err (first 8):", np.abs(got - ref).max(axis=(0, 1))[:8])
-    sr.set_option("use_dma", 1)
+    sr.set_option("kernel", 2)
 
 
 def sec_shader(sr):
@@ -157,7 +158,7 @@ def sec_perf():
     img = synth.make_image(3, w, h)
     d_in = torch.from_numpy(img).cuda()
     d_out = torch.empty((h * 4, w * 4, 3), dtype=torch.uint8, device="cuda")
-    variants = os.environ.get("RSR_PERF_VARIANTS", "dma=1,trunk_fp32=1;dma=1,trunk_fp32=0").split(";")
+    variants = os.environ.get("RSR_PERF_VARIANTS", "kernel=2,trunk_fp32=1;kernel=2,trunk_fp32=0;kernel=1,trunk_fp32=0").split(";")
     for var in variants:
         opts = dict(kv.split("=") for kv in var.split(",") if kv)
         for k, v in opts.items():

@@ -150,9 +150,14 @@ int rsr_get_profile(rsr_ctx* ctx, rsr_profile* out, int reset);
  * over the profiled calls since the last reset. */
 int rsr_get_conv_times(rsr_ctx* ctx, double* ms, int n, int reset);
 
-/* Engine knobs (optional).  key/value: "max_workspace_mb" (tile batch memory budget),
- * "trunk_fp32" (1: residual trunk kept in fp32 [default], 0: fp16 storage like the reference's
- * Vulkan path). */
+/* Engine knobs (optional).  key/value:
+ *   "max_workspace_mb"  tile-batch memory budget (default 65536)
+ *   "trunk_fp32"        0 [default]: every feature tensor incl. the residual trunk is stored as fp16, like the
+ *                       reference's Vulkan path (use_fp16_storage, realsr.cpp:45); 1: the trunk additionally lives
+ *                       in fp32 (halves the pre-quantise error, costs ~15 % throughput)
+ *   "kernel"            2 [default]: conv3x3_pipe (persistent, wave-specialised), 1: conv3x3_mfma
+ *   "use_dma"           kernel 1 only: LDS-DMA (1) or register staging (0)
+ *   "num_cu", "dbg"     profiling aids (persistent grid size, ablation bits of ConvArgs::dbg) */
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
 
 const char* rsr_last_error(const rsr_ctx* ctx); /* ctx may be NULL: last global (create/pack) error */

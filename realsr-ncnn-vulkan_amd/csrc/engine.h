@@ -52,7 +52,7 @@ struct Engine
     int tta = 0;
     int scale = 4, tilesize = 200, prepadding = 10;
     bool loaded = false;
-    bool trunk_fp32 = true;
+    bool trunk_fp32 = false; // residual trunk storage: fp16 like the reference Vulkan path (realsr.cpp:45); true = extra fp32 copy
     bool use_dma = true;
     int kernel_version = 2; // 2: conv3x3_pipe (persistent, wave-specialised), 1: conv3x3_mfma
     int num_cu = 256;

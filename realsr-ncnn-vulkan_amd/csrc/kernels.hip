@@ -435,6 +435,13 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
     constexpr int WITEMS = WROWS * 4;
     constexpr int WPASS = (WITEMS + 255) / 256;
     constexpr int STAGE = kPatchLds + WROWS * 64;
+    // EPI 3 ("outbox", NT == 1, act-only epilogue, >= 2 chunks per item): the compute waves only drop their finished
+    // block as fp16 into a 32-KiB LDS outbox (16 ds_write_b64 per wave) and go straight on to the next item; the
+    // LOADER waves -- idle between two DMA bursts -- drain it one barrier later with 16-B loads and fully coalesced
+    // 1-KiB global stores.  The store path (and its texture-addresser time) leaves the MFMA waves' critical path.
+    constexpr bool OUTBOX = (EPI == 3);
+    static_assert(!OUTBOX || NT == 1, "outbox epilogue is built for NT == 1");
+    constexpr int OUTBOX_OFF = 2 * STAGE + 256;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -458,11 +465,28 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
         const char* wbase = static_cast<const char*>(a.wpk);
         int t = 0;
         WorkItem nxt = a.items[first];
+        WorkItem prev = nxt;
+        // outbox drain (loader side): lane -> (column, 16-B piece) fixed, 8 passes walk the 16 rows two at a time
+        const int dcol = (ltid >> 2) & 31, dpiece = ltid & 3, drow0 = ltid >> 7;
+        const int dlds = OUTBOX_OFF + (drow0 * 32 + dcol) * 64 + ((dpiece ^ ((dcol >> 1) & 3)) << 4);
+        auto drain = [&](const WorkItem& pi) {
+            char* outp = const_cast<char*>(plane_ptr(a.out16, pi.slot, 0));
+            const int x = pi.x0 + dcol;
+#pragma unroll
+            for (int pass = 0; pass < 8; pass++)
+            {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + dlds + pass * (2 * 32 * 64));
+                const int y = pi.y0 + pass * 2 + drow0;
+                if (y < pi.H && x < pi.W) *reinterpret_cast<uint4*>(outp + ((long long)y * pi.W + x) * 64 + dpiece * 16) = v;
+            }
+        };
         for (int r = 0; r < nmine; r++)
         {
             // the descriptor of item r was fetched one item ago; item r+1's is requested now and lands while
             // this item's stages stream (no dependent global load sits in front of a DMA issue)
+            const WorkItem before = prev;
             const WorkItem it = nxt;
+            prev = it;
             if (r + 1 < nmine) nxt = a.items[first + (r + 1) * nj];
             const int H = it.H, W = it.W, Wi = UPS ? (W >> 1) : W;
             int srcoff[kPatchIters];
@@ -487,6 +511,9 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                     // that buffer t&1 is free.
                     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 }
+                // the barrier just passed at (r >= 1, ck == 1) is the one the compute waves reached after writing the
+                // previous item's outbox; they will not write it again before the NEXT barrier (>= 2 chunks per item)
+                if (OUTBOX && r > 0 && ck == 1) drain(before);
                 char* buf = smem + (t & 1) * STAGE;
                 const char* plane = (ck < a.n0) ? plane_ptr(a.src0, it.slot, ck) : plane_ptr(a.src1, it.slot, ck - a.n0);
                 const char* wsrc = wbase + (long long)ck * (WROWS * 64);
@@ -509,6 +536,11 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
             }
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // barrier B_{S-1}
+        if (OUTBOX)
+        {
+            asm volatile("s_barrier" ::: "memory"); // B_S: the last item's outbox is complete
+            drain(prev);
+        }
         return;
     }
 
@@ -551,7 +583,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
         // All this barrier must order is LDS: the DMA writes of stage s (drained by the loaders before they
         // arrive) against our ds_reads below, and our reads of stage s-1 (consumed by MFMAs already) against
         // the loaders' next fill.
-        asm volatile("s_barrier" ::: "memory"); // barrier B_s: stage s is in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // barrier B_s: stage s is in LDS (our outbox writes landed)
         const char* buf = smem + (s & 1) * STAGE;
         if (!(a.dbg & 2))
         {
@@ -607,7 +639,28 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 f32x4 bq[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(bias_lds + ntw * 32 + q * 8 + hi * 4);
-                if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+                if (OUTBOX)
+                {
+                    const float slope = a.lrelu ? 0.2f : 1.f;
+                    char* ob = smem + OUTBOX_OFF + l32 * 64 + hi * 8;
+                    const int swz = (l32 >> 1) & 3;
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                        {
+                            half4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                            {
+                                const float v = acc[rr][q * 4 + e] + bq[q][e];
+                                o[e] = (_Float16)fmaxf(v, v * slope);
+                            }
+                            *reinterpret_cast<half4*>(ob + (wrow * 4 + rr) * (32 * 64) + ((q ^ swz) << 4)) = o;
+                        }
+                }
+                else if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+                else if (EPI == 3) {}
                 else if (it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W)
                     conv_epilogue_t<EPI, false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
                 else
@@ -623,12 +676,13 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 for (int e = 0; e < 16; e++) acc[rr][e] = 0.f;
         }
     }
+    if (OUTBOX) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // B_S: hand the last outbox to the loaders
 }
 
 template <int NT, bool UPS, int EPI>
 static void launch_conv_pipe_t(const ConvArgs& a, int ncu, hipStream_t st)
 {
-    const size_t lds = 2 * (size_t(kPatchLds) + size_t(9 * NT * 32 * 64)) + 256; // two stages + bias
+    const size_t lds = 2 * (size_t(kPatchLds) + size_t(9 * NT * 32 * 64)) + 256 + (EPI == 3 ? 32768 : 0); // two stages + bias (+ outbox)
     static bool attr_set = false;
     if (!attr_set)
     {
@@ -652,10 +706,12 @@ void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st)
         if (a.res1_kind == 0 && a.res2_kind == 0) epi = 1;
         else if (a.res1_kind == 1 && (a.res2_kind == 0 || a.res2_kind == 1)) epi = 2;
     }
+    if (epi == 1 && nt == 1 && a.n0 + a.n1 >= 2 && !(a.dbg & 32)) epi = 3; // outbox: stores by the loader waves
 #define RSR_PIPE(NT_, UPS_)                                                   \
     do                                                                        \
     {                                                                         \
-        if (epi == 1) launch_conv_pipe_t<NT_, UPS_, 1>(a, ncu, st);           \
+        if (epi == 3) launch_conv_pipe_t<1, UPS_, 3>(a, ncu, st);             \
+        else if (epi == 1) launch_conv_pipe_t<NT_, UPS_, 1>(a, ncu, st);      \
         else if (epi == 2) launch_conv_pipe_t<NT_, UPS_, 2>(a, ncu, st);      \
         else launch_conv_pipe_t<NT_, UPS_, 0>(a, ncu, st);                    \
     } while (0)

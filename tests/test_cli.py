@@ -1,0 +1,153 @@
+"""CLI (realsr-ncnn-vulkan_amd/bin/realsr-hip): flag surface and validation of the reference tool
+(main.cpp:101-115, :484-603), codecs (image_io.h), and -- on the GPU box -- an end-to-end directory run."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import realsr_ncnn_vulkan_amd as R
+from realsr_ncnn_vulkan_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "realsr-ncnn-vulkan_amd", "bin", "realsr-hip")
+CSRC = os.path.join(ROOT, "realsr-ncnn-vulkan_amd", "csrc")
+
+
+def write_png(path, img, filt=0):
+    """Independent PNG writer (numpy + zlib): 8-bit RGB/RGBA/gray, given filter type per row (0 or 2)."""
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else img.shape[2]
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    rows = img.reshape(h, w * c).astype(np.uint8)
+    if filt == 2:
+        up = np.vstack([np.zeros((1, w * c), np.uint8), rows[:-1]])
+        rows = (rows.astype(np.int16) - up).astype(np.uint8)
+    raw = b"".join(bytes([filt]) + r.tobytes() for r in rows)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def read_png(path):
+    """Independent PNG reader for what save_png emits (8-bit RGB/RGBA, any filter)."""
+    d = open(path, "rb").read()
+    assert d[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat = 8, b""
+    while pos < len(d):
+        n, t = struct.unpack(">I4s", d[pos:pos + 8])
+        body = d[pos + 8:pos + 8 + n]
+        if t == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+        elif t == b"IDAT":
+            idat += body
+        pos += 12 + n
+    c = {2: 3, 6: 4}[ctype]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * c + 1)
+    out = np.zeros((h, w * c), np.uint8)
+    for y in range(h):
+        ft, row = raw[y, 0], raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            out[y] = row
+        elif ft == 1:
+            for i in range(c):
+                out[y, i::c] = np.cumsum(row[i::c]) & 255
+        elif ft == 2:
+            out[y] = (row + (out[y - 1] if y else 0)) & 255
+        else:
+            raise AssertionError("unexpected filter %d" % ft)
+    return out.reshape(h, w, c)
+
+
+@pytest.fixture(scope="module")
+def io_harness(tmp_path_factory):
+    d = tmp_path_factory.mktemp("io")
+    src = d / "t_io.cpp"
+    src.write_text('#include "image_io.h"\nint main(int c, char** v){Image im; std::string e = imgio::load_image(v[1], im);'
+                   'if(!e.empty()){fprintf(stderr,"%s\\n",e.c_str());return 1;} e = imgio::save_png(v[2], im);'
+                   'if(!e.empty()){fprintf(stderr,"%s\\n",e.c_str());return 2;} printf("%d %d %d\\n",im.w,im.h,im.elempack);return 0;}\n')
+    exe = d / "t_io"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", CSRC, "-o", str(exe), str(src), "-lz"])
+    return str(exe)
+
+
+@pytest.mark.parametrize("shape,filt", [((13, 17, 3), 0), ((9, 20, 4), 2), ((11, 7), 0), ((6, 5, 2), 2)])
+def test_png_codec_roundtrip(io_harness, tmp_path, shape, filt):
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    write_png(tmp_path / "in.png", img, filt)
+    out = subprocess.check_output([io_harness, str(tmp_path / "in.png"), str(tmp_path / "out.png")]).decode().split()
+    got = read_png(tmp_path / "out.png")
+    if img.ndim == 2:  # gray -> RGB (main.cpp:247-252)
+        want = np.repeat(img[:, :, None], 3, 2)
+    elif img.shape[2] == 2:  # gray+alpha -> RGBA (main.cpp:253-260)
+        want = np.concatenate([np.repeat(img[:, :, :1], 3, 2), img[:, :, 1:]], 2)
+    else:
+        want = img
+    assert [int(v) for v in out] == [want.shape[1], want.shape[0], want.shape[2]]
+    assert (got == want).all()
+
+
+def test_pnm_and_unsupported_formats(io_harness, tmp_path):
+    img = np.arange(5 * 4 * 3, dtype=np.uint8).reshape(5, 4, 3)
+    with open(tmp_path / "a.ppm", "wb") as f:
+        f.write(b"P6\n# c\n4 5\n255\n" + img.tobytes())
+    subprocess.check_call([io_harness, str(tmp_path / "a.ppm"), str(tmp_path / "o.png")], stdout=subprocess.DEVNULL)
+    assert (read_png(tmp_path / "o.png") == img).all()
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 20)
+    r = subprocess.run([io_harness, str(tmp_path / "x.jpg"), str(tmp_path / "o2.png")], capture_output=True)
+    assert r.returncode == 1 and b"jpeg" in r.stderr
+
+
+def run_cli(*args):
+    return subprocess.run([CLI] + list(args), capture_output=True, text=True)
+
+
+def test_cli_flag_validation(tmp_path):
+    assert os.path.exists(CLI), "run __graft_entry__.build() first"
+    r = run_cli()
+    assert r.returncode != 0 and "Usage:" in r.stderr and "-j load:proc:save" in r.stderr
+    png = tmp_path / "a.png"
+    write_png(png, np.zeros((4, 4, 3), np.uint8))
+    out = str(tmp_path / "o.png")
+    assert "invalid scale argument" in run_cli("-i", str(png), "-o", out, "-s", "2").stderr
+    assert "invalid tilesize argument" in run_cli("-i", str(png), "-o", out, "-t", "16").stderr
+    assert "invalid tilesize argument" in run_cli("-i", str(png), "-o", out, "-t", "64,64").stderr
+    assert "invalid jobs_proc thread count argument" in run_cli("-i", str(png), "-o", out, "-g", "0,1", "-j", "1:2,2,2:2").stderr
+    assert "invalid thread count argument" in run_cli("-i", str(png), "-o", out, "-j", "0:2:2").stderr
+    assert "invalid outputpath extension type" in run_cli("-i", str(png), "-o", str(tmp_path / "o.bmp")).stderr
+    assert "unknown model dir type" in run_cli("-i", str(png), "-o", out, "-m", "models-foo").stderr
+    assert "either file or directory" in run_cli("-i", str(png), "-o", str(tmp_path)).stderr
+    assert "no CPU fallback" in run_cli("-i", str(png), "-o", out, "-g", "-1").stderr
+    assert "not built in" in run_cli("-i", str(png), "-o", str(tmp_path / "o.jpg")).stderr
+
+
+@pytest.mark.gpu
+def test_cli_directory_run_matches_library(tmp_path, model_dir):
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    outd.mkdir()
+    imgs = {"a": synth.make_image(31, 40, 30), "b": synth.make_image(32, 33, 21, 4), "a_dup": synth.make_image(33, 24, 24)}
+    write_png(ind / "a.png", imgs["a"])
+    write_png(ind / "b.png", imgs["b"])
+    with open(ind / "a.ppm", "wb") as f:  # same stem as a.png -> the collision rule renames its output (main.cpp:625-637)
+        f.write(b"P6\n24 24\n255\n" + imgs["a_dup"].tobytes())
+    r = run_cli("-i", str(ind), "-o", str(outd), "-m", model_dir, "-t", "32", "-j", "2:2:2", "-v")
+    assert r.returncode == 0, r.stderr
+    assert "both a.ppm and a.png output a.png" in r.stderr or "both a.png and a.ppm" in r.stderr
+    assert sorted(os.listdir(outd)) == ["a.png", "a.ppm.png", "b.png"]
+    sr = R.RealSR(0)
+    sr.load(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
+    sr.tilesize = 32
+    names = sorted(os.listdir(ind))  # a.png, a.ppm, b.png: the first of a collision keeps the plain name
+    first, second = names[0], names[1]
+    key = {"a.png": "a", "a.ppm": "a_dup"}
+    assert (read_png(outd / (first.split(".")[0] + ".png")) == sr.process(imgs[key[first]])).all()
+    assert (read_png(outd / (second + ".png")) == sr.process(imgs[key[second]])).all()
+    assert (read_png(outd / "b.png") == sr.process(imgs["b"])).all()
+    sr.close()

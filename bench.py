@@ -167,7 +167,7 @@ def main():
             res["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
-                "kernel": "rsr::conv3x3_mfma<NT,UPS,DMA> (all 351 convs x 60 tiles)",
+                "kernel": "rsr::conv3x3_pipe<NT,UPS,EPI> (all 351 convs x 60 tiles)",
                 "launches": prof["conv_launches"],
                 "avg_launch_us": round(prof["conv_ms"] * 1e3 / max(prof["conv_launches"], 1), 2),
                 "algorithmic_flop_per_launch_avg": round(prof["conv_flops"] / max(prof["conv_launches"], 1)),

@@ -255,22 +255,38 @@ int Engine::build_plan(int w, int h, int c)
     return RSR_OK;
 }
 
-int Engine::ensure_workspace(int nslots, long long cap)
+// Every fp16 plane that a convolution may read carries a 64-byte zero GUARD in front of pixel 0 (plane = [guard |
+// H*W*64 B]).  The LDS-DMA loaders address a plane as (uniform base, 32-bit lane offset); lanes whose patch pixel
+// lies outside the image use offset 0 = the guard, i.e. conv zero padding without a second base pointer.  Guards
+// are zeroed when a buffer is (re)allocated and never written afterwards.
+int Engine::ensure_zeroed(DevBuf& b, size_t bytes, bool layout_changed, hipStream_t st)
 {
-    const size_t n = size_t(nslots), c = size_t(cap);
+    const void* before = b.p;
+    const size_t had = b.bytes;
+    const int rc = ensure(b, bytes);
+    if (rc != RSR_OK) return rc;
+    // a new plane stride moves the guards onto bytes that used to hold pixels: zero the used extent again
+    if (b.p != before || b.bytes != had || layout_changed) HIP_TRY(hipMemsetAsync(b.p, 0, bytes, st)); // same stream as the kernels that follow
+    return RSR_OK;
+}
+
+int Engine::ensure_workspace(int nslots, long long cap, hipStream_t st)
+{
+    const size_t n = size_t(nslots), c = size_t(cap), G = size_t(kGuard);
+    const bool lc = (cap != ws_cap_px); // plane stride (hence guard positions) depends on the slot capacity
     int rc;
-    if ((rc = ensure(b_in, n * c * 64)) != RSR_OK) return rc;
-    if ((rc = ensure(b_fea, n * c * 128)) != RSR_OK) return rc;
+    if ((rc = ensure_zeroed(b_in, n * (c * 64 + G), lc, st)) != RSR_OK) return rc;
+    if ((rc = ensure_zeroed(b_fea, n * 2 * (c * 64 + G), lc, st)) != RSR_OK) return rc;
     for (int i = 0; i < 3; i++)
-        if ((rc = ensure(b_rdb[i], n * c * 384)) != RSR_OK) return rc;
+        if ((rc = ensure_zeroed(b_rdb[i], n * 6 * (c * 64 + G), lc, st)) != RSR_OK) return rc;
     if (trunk_fp32)
     {
         if ((rc = ensure(b_t32, n * c * 256)) != RSR_OK) return rc;
         if ((rc = ensure(b_r32, n * c * 256)) != RSR_OK) return rc;
     }
-    if ((rc = ensure(b_up1, n * c * 512)) != RSR_OK) return rc;
-    if ((rc = ensure(b_up2, n * c * 2048)) != RSR_OK) return rc;
-    if ((rc = ensure(b_hr, n * c * 2048)) != RSR_OK) return rc;
+    if ((rc = ensure_zeroed(b_up1, n * 2 * (c * 256 + G), lc, st)) != RSR_OK) return rc;
+    if ((rc = ensure_zeroed(b_up2, n * 2 * (c * 1024 + G), lc, st)) != RSR_OK) return rc;
+    if ((rc = ensure_zeroed(b_hr, n * 2 * (c * 1024 + G), lc, st)) != RSR_OK) return rc;
     if ((rc = ensure(b_out3, n * c * 96)) != RSR_OK) return rc;
     ws_slots = nslots;
     ws_cap_px = cap;
@@ -343,9 +359,16 @@ void Engine::collect_profile(hipStream_t st)
 void Engine::run_network(const Plan::Batch& b, hipStream_t st)
 {
     const long long cap = ws_cap_px;
-    const long long pb16 = cap * 64, pb32 = cap * 128;
+    const long long pb16 = cap * 64 + kGuard, pb32 = cap * 128; // fp16 planes are guarded (see ensure_workspace)
     auto PS = [](const DevBuf& buf, long long planes_per_slot, long long plane_bytes, int plane_off) {
-        PlaneSrc s;
+        PlaneSrc s; // base = pixel 0 of plane `plane_off` of slot 0
+        s.base = static_cast<const char*>(buf.p) + (long long)plane_off * plane_bytes + kGuard;
+        s.slot_stride = planes_per_slot * plane_bytes;
+        s.plane_stride = plane_bytes;
+        return s;
+    };
+    auto PS32 = [](const DevBuf& buf, long long planes_per_slot, long long plane_bytes, int plane_off) {
+        PlaneSrc s; // fp32 trunk planes: never a DMA source, no guard
         s.base = static_cast<const char*>(buf.p) + (long long)plane_off * plane_bytes;
         s.slot_stride = planes_per_slot * plane_bytes;
         s.plane_stride = plane_bytes;
@@ -379,7 +402,7 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         ci++;
     };
     const PlaneSrc fea = PS(b_fea, 2, pb16, 0);
-    const PlaneSrc t32 = PS(b_t32, 2, pb32, 0), r32 = PS(b_r32, 2, pb32, 0);
+    const PlaneSrc t32 = PS32(b_t32, 2, pb32, 0), r32 = PS32(b_r32, 2, pb32, 0);
     auto rdb_x = [&](int i) { return PS(b_rdb[i], 6, pb16, 0); };
     auto rdb_d = [&](int i, int k) { return PS(b_rdb[i], 6, pb16, 2 + k); };
 
@@ -427,7 +450,7 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         a.out16 = rdb_x(1);
         go(a);
     }
-    const PlaneSrc up1 = PS(b_up1, 2, pb16 * 4, 0), up2 = PS(b_up2, 2, pb16 * 16, 0), hr = PS(b_hr, 2, pb16 * 16, 0);
+    const PlaneSrc up1 = PS(b_up1, 2, cap * 256 + kGuard, 0), up2 = PS(b_up2, 2, cap * 1024 + kGuard, 0), hr = PS(b_hr, 2, cap * 1024 + kGuard, 0);
     { // nearest x2 + upconv1 + lrelu   (x4.param:996-997)
         ConvArgs a = base_args(0, 1);
         a.src0 = rdb_x(1); a.n0 = 2;
@@ -467,7 +490,7 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
     if (!st) st = stream;
     int rc = build_plan(w, h, c);
     if (rc != RSR_OK) return rc;
-    rc = ensure_workspace(plan.slots_per_batch, plan.cap_px);
+    rc = ensure_workspace(plan.slots_per_batch, plan.cap_px, st);
     if (rc != RSR_OK) return rc;
     mark_begin(st);
     for (const Plan::Batch& b : plan.batches)
@@ -478,8 +501,8 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
         pa.tiles = b.d_tiles;
         pa.ntiles = b.ntiles;
         pa.tta = tta;
-        pa.in_plane = b_in.p;
-        pa.slot_stride = plan.cap_px * 64;
+        pa.in_plane = static_cast<char*>(b_in.p) + kGuard;
+        pa.slot_stride = plan.cap_px * 64 + kGuard;
         pa.bgr = 0;
         launch_preproc_tiles(pa, plan.max_tw, plan.max_th, st);
         mark(0, 0, b.px[0] / (tta ? 8 : 1) * c + b.px[0] * 64, st);
@@ -557,13 +580,13 @@ int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out)
         HIP_TRY(hipMemcpy(d, b.items[l].data(), b.items[l].size() * sizeof(WorkItem), hipMemcpyHostToDevice));
         d += al256(b.items[l].size() * sizeof(WorkItem));
     }
-    int rc = ensure_workspace(1, plan.cap_px);
+    int rc = ensure_workspace(1, plan.cap_px, stream);
     if (rc != RSR_OK) return rc;
     const size_t npx = size_t(w) * h;
     DevBuf tmp;
     if ((rc = ensure(tmp, npx * 6)) != RSR_OK) return rc;
     HIP_TRY(hipMemcpy(tmp.p, in, npx * 6, hipMemcpyHostToDevice));
-    launch_planar3_to_plane(static_cast<const uint16_t*>(tmp.p), w, h, b_in.p, stream);
+    launch_planar3_to_plane(static_cast<const uint16_t*>(tmp.p), w, h, static_cast<char*>(b_in.p) + kGuard, stream);
     const bool was = profiling;
     profiling = false;
     run_network(b, stream);
@@ -598,9 +621,10 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     const int H = ups ? 2 * h : h, W = ups ? 2 * w : w;
     const size_t ipx = size_t(h) * w, opx = size_t(H) * W;
     // planar [cin][h][w] -> planes [np][h][w][32]
-    std::vector<uint16_t> hin(size_t(np) * ipx * 32, 0), hout(size_t(nt) * opx * 32, 0);
+    const size_t ipl = ipx * 32 + kGuard / 2; // halfs per guarded input plane
+    std::vector<uint16_t> hin(size_t(np) * ipl, 0), hout(size_t(nt) * opx * 32, 0);
     for (int ch = 0; ch < cin; ch++)
-        for (size_t p = 0; p < ipx; p++) hin[(size_t(ch / 32) * ipx + p) * 32 + size_t(ch % 32)] = in[size_t(ch) * ipx + p];
+        for (size_t p = 0; p < ipx; p++) hin[size_t(ch / 32) * ipl + kGuard / 2 + p * 32 + size_t(ch % 32)] = in[size_t(ch) * ipx + p];
     DevBuf d_w, d_in, d_out, d_tab;
     std::vector<WorkItem> items;
     for (int y0 = 0; y0 < H; y0 += kBlkH)
@@ -623,7 +647,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     (void)hipMemcpy(static_cast<char*>(d_tab.p) + 256, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice);
     ConvArgs a;
     std::memset(&a, 0, sizeof a);
-    a.src0 = PlaneSrc{d_in.p, 0, (long long)ipx * 64};
+    a.src0 = PlaneSrc{static_cast<char*>(d_in.p) + kGuard, 0, (long long)ipx * 64 + kGuard};
     a.n0 = np;
     a.lvl_in = 0;
     a.lvl_out = ups ? 1 : 0;

@@ -103,8 +103,9 @@ struct Engine
                   uint16_t* out);
 
     int ensure(DevBuf& b, size_t bytes);
+    int ensure_zeroed(DevBuf& b, size_t bytes, bool layout_changed, hipStream_t st);
     int build_plan(int w, int h, int c);
-    int ensure_workspace(int nslots, long long cap_px);
+    int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
     void run_network(const Plan::Batch& b, hipStream_t st);
     void mark_begin(hipStream_t st);
     void mark(int cls, double flops, double bytes, hipStream_t st, int conv_index = -1);

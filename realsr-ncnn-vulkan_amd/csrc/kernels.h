@@ -20,6 +20,7 @@ constexpr int kBlkH = 16, kBlkW = 32;          // output block of one workgroup
 constexpr int kPatchH = kBlkH + 2, kPatchW = kBlkW + 2;
 constexpr int kPatchPx = kPatchH * kPatchW;     // 612
 constexpr int kPatchBytes = kPatchPx * 64;      // 39168
+constexpr int kGuard = 64;                      // zero bytes in front of every conv-input plane (LDS-DMA source for padding)
 constexpr int kPatchLds = 39936;                // LDS bytes reserved for the patch: 39 wave-sized (1 KiB) LDS-DMA pieces
 
 struct WorkItem // 32 bytes: one aligned 2 x 16-byte fetch gives a workgroup everything about its block

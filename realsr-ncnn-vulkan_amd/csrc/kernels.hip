@@ -144,28 +144,31 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& a, f32x16 (&acc)
     long long off[4];
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) off[rr] = ((long long)(y0 + wrow * 4 + rr) * W + x) * 64;
-    half4 r1[4][4], r2[4][4];
+    half4 r1[4][4];
     const bool has2 = (EPI == 2) && a.res2_kind == 1;
+    const char* r2p = nullptr;
     if (EPI == 2)
     {
         const char* r1p = plane_ptr(a.res1, slot, nt) + hi * 8;
-        const char* r2p = has2 ? plane_ptr(a.res2, slot, nt) + hi * 8 : r1p;
+        r2p = has2 ? plane_ptr(a.res2, slot, nt) + hi * 8 : r1p;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++)
         {
             const bool ok = xin && (!CHECK || y0 + wrow * 4 + rr < H);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-            {
-                r1[rr][q] = ok ? *reinterpret_cast<const half4*>(r1p + off[rr] + q * 16) : half4{0, 0, 0, 0};
-                if (has2) r2[rr][q] = ok ? *reinterpret_cast<const half4*>(r2p + off[rr] + q * 16) : half4{0, 0, 0, 0};
-            }
+            for (int q = 0; q < 4; q++) r1[rr][q] = ok ? *reinterpret_cast<const half4*>(r1p + off[rr] + q * 16) : half4{0, 0, 0, 0};
         }
     }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++)
     {
         const bool ok = xin && (!CHECK || y0 + wrow * 4 + rr < H);
+        half4 r2[4]; // second residual (every third dense block only): fetched per row, 8 registers instead of 32
+        if (has2)
+        {
+#pragma unroll
+            for (int q = 0; q < 4; q++) r2[q] = ok ? *reinterpret_cast<const half4*>(r2p + off[rr] + q * 16) : half4{0, 0, 0, 0};
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++)
         {
@@ -178,7 +181,7 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& a, f32x16 (&acc)
                 if (EPI == 2)
                 {
                     v = v * a.s1 + (float)r1[rr][q][e];
-                    if (has2) v = v * a.s2 + (float)r2[rr][q][e];
+                    if (has2) v = v * a.s2 + (float)r2[q][e];
                 }
                 o[e] = (_Float16)v;
             }
@@ -461,8 +464,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
     {
         // ================= loader waves =================
         const int lw = wave - NCW, ltid = lw * 64 + lane;
-        const char* zp = static_cast<const char*>(a.zeros);
-        const char* wbase = static_cast<const char*>(a.wpk);
+                const char* wbase = static_cast<const char*>(a.wpk);
         int t = 0;
         WorkItem nxt = a.items[first];
         WorkItem prev = nxt;
@@ -489,7 +491,8 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
             prev = it;
             if (r + 1 < nmine) nxt = a.items[first + (r + 1) * nj];
             const int H = it.H, W = it.W, Wi = UPS ? (W >> 1) : W;
-            int srcoff[kPatchIters];
+            // byte offset of every patch item of this lane from (plane pixel 0 - kGuard); 0 = the plane's zero guard
+            unsigned srcoff[kPatchIters];
 #pragma unroll
             for (int i = 0; i < kPatchIters; i++)
             {
@@ -500,7 +503,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 const bool ok = (jj < kPatchItems) && gy >= 0 && gy < H && gx >= 0 && gx < W;
                 const int sy = UPS ? (gy >> 1) : gy, sx = UPS ? (gx >> 1) : gx;
                 // LDS item jj receives logical 16-B slot sl ^ ((column >> 2) & 3) of its pixel (column swizzle)
-                srcoff[i] = ok ? ((sy * Wi + sx) * 64 + ((sl ^ ((cc >> 2) & 3)) << 4)) : -1;
+                srcoff[i] = ok ? unsigned(kGuard + (sy * Wi + sx) * 64 + ((sl ^ ((cc >> 2) & 3)) << 4)) : 0u;
             }
             for (int ck = 0; ck < nplanes; ck++, t++)
             {
@@ -514,24 +517,23 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 // the barrier just passed at (r >= 1, ck == 1) is the one the compute waves reached after writing the
                 // previous item's outbox; they will not write it again before the NEXT barrier (>= 2 chunks per item)
                 if (OUTBOX && r > 0 && ck == 1) drain(before);
-                char* buf = smem + (t & 1) * STAGE;
-                const char* plane = (ck < a.n0) ? plane_ptr(a.src0, it.slot, ck) : plane_ptr(a.src1, it.slot, ck - a.n0);
-                const char* wsrc = wbase + (long long)ck * (WROWS * 64);
-#pragma unroll
-                for (int i = 0; i < kPatchIters; i++)
+                char* buf = smem + (t & 1) * STAGE + lw * 1024;
+                const char* gbase = ((ck < a.n0) ? plane_ptr(a.src0, it.slot, ck) : plane_ptr(a.src1, it.slot, ck - a.n0)) - kGuard;
+                const char* wsrc = wbase + (long long)ck * (WROWS * 64) + (lw * 64 + lane) * 16;
+                if (!(a.dbg & 1))
                 {
-                    const char* src = srcoff[i] >= 0 ? plane + srcoff[i] : zp;
-                    if ((i * 256 + lw * 64) * 16 < kPatchLds && !(a.dbg & 1)) // wave-uniform: the 40th 1-KiB piece does not exist
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                         (__attribute__((address_space(3))) void*)(buf + (i * 256 + lw * 64) * 16), 16, 0, 0);
-                }
 #pragma unroll
-                for (int i = 0; i < WPASS; i++)
-                {
-                    const int jw = i * 256 + lw * 64;
-                    if (jw < WITEMS && !(a.dbg & 1))
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (jw + lane) * 16),
-                                                         (__attribute__((address_space(3))) void*)(buf + kPatchLds + jw * 16), 16, 0, 0);
+                    for (int i = 0; i < kPatchIters - 1; i++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
+                                                         (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
+                    if (lw < 3) // the patch region is 39 one-KiB pieces: the last pass has only three
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
+                                                         (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < WPASS; i++)
+                        if (i * 256 + lw * 64 < WITEMS)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 4096),
+                                                             (__attribute__((address_space(3))) void*)(buf + kPatchLds + i * 4096), 16, 0, 0);
                 }
             }
         }
@@ -591,10 +593,13 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
 #define RSR_LOAD_STEP(X, Wf, T)                                                                                     \
     {                                                                                                                \
         constexpr int dx_ = (T) >> 1, cb_ = (T)&1;                                                                   \
-        _Pragma("unroll") for (int rr = 0; rr < 6; rr++)                                                             \
-            X[rr] = *reinterpret_cast<const half8*>(buf + ((xcol[dx_] ^ (cb_ << 5)) + rr * (kPatchW * 64)));         \
         _Pragma("unroll") for (int dy = 0; dy < 3; dy++)                                                             \
+        {                                                                                                            \
+            X[dy] = *reinterpret_cast<const half8*>(buf + ((xcol[dx_] ^ (cb_ << 5)) + dy * (kPatchW * 64)));         \
             Wf[dy] = *reinterpret_cast<const half8*>(buf + ((woff ^ (cb_ << 5)) + (dy * 3 + dx_) * (NT * 32 * 64))); \
+        }                                                                                                            \
+        _Pragma("unroll") for (int rr = 3; rr < 6; rr++)                                                             \
+            X[rr] = *reinterpret_cast<const half8*>(buf + ((xcol[dx_] ^ (cb_ << 5)) + rr * (kPatchW * 64)));         \
     }
 #define RSR_MFMA_STEP(X, Wf)                                                                                         \
     {                                                                                                                \
@@ -615,20 +620,21 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
         RSR_MFMA_STEP(X1, W1)
 #undef RSR_LOAD_STEP
 #undef RSR_MFMA_STEP
-        // Pin the issue order (hipcc otherwise sinks every ds_read next to its MFMA with lgkmcnt(0) in
-        // front): fragments of steps 0,1 first, then each step's 12 MFMAs interleaved 1:1 with the 9
-        // ds_reads of the step two ahead.  Masks: 0x8 MFMA, 0x100 DS read.
+        // Pin the issue order (hipcc otherwise sinks every ds_read next to its MFMA behind lgkmcnt(0)).  Fragments of
+        // steps 0,1 first; then, per step t, the loads of step t+2 are issued INTO THE REGISTERS STEP t FREES, in the
+        // order it frees them: after the dy=0 MFMAs {X[0], W[0]} are dead, after dy=1 {X[1], W[1]}, after dy=2 the
+        // rest -- two fragment sets stay live, not three (at 3 waves/SIMD the NT=2 kernel has 168 VGPRs).
+        // Masks: 0x8 MFMA, 0x100 DS read.
         __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
 #pragma unroll
         for (int t = 0; t < 4; t++)
         {
-#pragma unroll
-            for (int i = 0; i < 9; i++)
-            {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
         }

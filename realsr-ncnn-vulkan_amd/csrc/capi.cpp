@@ -308,9 +308,11 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         ctx->e.use_dma = value != 0;
     else if (k == "kernel")
     {
-        if (value != 1 && value != 2) return ctx->e.fail(RSR_E_ARG, "kernel must be 1 or 2");
+        if (value < 1 || value > 3) return ctx->e.fail(RSR_E_ARG, "kernel must be 1, 2 or 3");
         ctx->e.kernel_version = int(value);
     }
+    else if (k == "ring_nt2")
+        ctx->e.ring_nt2 = value != 0;
     else if (k == "dbg")
         ctx->e.dbg = int(value);
     else if (k == "num_cu")

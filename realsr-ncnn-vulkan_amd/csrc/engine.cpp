@@ -100,7 +100,7 @@ int Engine::load_blob_device(const void* data, size_t bytes)
     if (bytes < head.size()) return fail(RSR_E_FORMAT, "packed blob too small");
     HIP_TRY(hipMemcpy(head.data(), data, head.size(), hipMemcpyDeviceToHost));
     const PackedHeader* H = reinterpret_cast<const PackedHeader*>(head.data());
-    if (H->magic != kPackedMagic || H->version != 1 || H->nconv != uint32_t(kNumConvs) || H->total_bytes != bytes)
+    if (H->magic != kPackedMagic || H->version != 2 || H->nconv != uint32_t(kNumConvs) || H->total_bytes != bytes)
         return fail(RSR_E_FORMAT, "packed blob header mismatch");
     int rc = ensure(blob, bytes);
     if (rc != RSR_OK) return rc;
@@ -382,6 +382,7 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         std::memset(&a, 0, sizeof a);
         const PackedConv& c = convs[size_t(ci)];
         a.wpk = blobp + c.w_off;
+        a.wfrag = blobp + c.wf_off;
         a.bias = reinterpret_cast<const float*>(blobp + c.b_off);
         a.lrelu = (c.act == 2);
         a.lvl_in = lvl_in;
@@ -396,7 +397,8 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
     };
     auto go = [&](ConvArgs& a) {
         const PackedConv& c = convs[size_t(ci)];
-        if (kernel_version == 2) launch_conv_pipe(a, int(c.nt), num_cu, st);
+        if (kernel_version == 3 && (c.nt == 1 || ring_nt2) && launch_conv_ring(a, int(c.nt), num_cu, st)) {}
+        else if (kernel_version >= 2) launch_conv_pipe(a, int(c.nt), num_cu, st);
         else launch_conv(a, int(c.nt), use_dma, st);
         mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out], 0, st, ci);
         ci++;
@@ -652,6 +654,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     a.lvl_in = 0;
     a.lvl_out = ups ? 1 : 0;
     a.wpk = static_cast<const char*>(d_w.p) + pc.w_off;
+    a.wfrag = static_cast<const char*>(d_w.p) + pc.wf_off;
     a.bias = reinterpret_cast<const float*>(static_cast<const char*>(d_w.p) + pc.b_off);
     a.lrelu = lrelu;
     a.s1 = a.s2 = 1.f;
@@ -660,7 +663,8 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     a.nitems = int(items.size());
     a.dims = static_cast<const TileDim*>(d_tab.p);
     a.zeros = zeros.p;
-    if (kernel_version == 2) launch_conv_pipe(a, nt, num_cu, stream);
+    if (kernel_version == 3 && (nt == 1 || ring_nt2) && launch_conv_ring(a, nt, num_cu, stream)) {}
+    else if (kernel_version >= 2) launch_conv_pipe(a, nt, num_cu, stream);
     else launch_conv(a, nt, use_dma, stream);
     hipError_t he = hipStreamSynchronize(stream);
     if (he == hipSuccess) he = hipGetLastError();

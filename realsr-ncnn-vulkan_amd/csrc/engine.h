@@ -54,8 +54,9 @@ struct Engine
     bool loaded = false;
     bool trunk_fp32 = false; // residual trunk storage: fp16 like the reference Vulkan path (realsr.cpp:45); true = extra fp32 copy
     bool use_dma = true;
-    int kernel_version = 2; // 2: conv3x3_pipe (persistent, wave-specialised), 1: conv3x3_mfma
+    int kernel_version = 3; // 3: conv3x3_ring, 2: conv3x3_pipe, 1: conv3x3_mfma
     int num_cu = 256;
+    bool ring_nt2 = false; // use conv3x3_ring also for 64-output-channel convs (slower there: 168-VGPR budget)
     int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
     long long max_workspace_mb = 65536;
     hipStream_t stream = nullptr;

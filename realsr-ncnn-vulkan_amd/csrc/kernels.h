@@ -51,6 +51,7 @@ struct ConvArgs
     int lvl_out; // output resolution = LR << lvl_out (lvl_out == lvl_in + 1 for the nearest-x2 fused convs)
     // weights: packed LDS images, one per 32-cin chunk; bias fp32 [NT*32]
     const void* wpk;
+    const void* wfrag; // fragment-major weights (model.h PackedConv::wf_off), read directly by conv3x3_ring's MFMA waves
     const float* bias;
     int lrelu; // LeakyReLU(0.2) on (acc + bias)
     // residual stages: v = v*s + r  (r fp32 plane or fp16 plane)
@@ -74,6 +75,7 @@ struct ConvArgs
 
 void launch_conv(const ConvArgs& a, int nt, bool dma, hipStream_t st);
 void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st); // persistent wave-specialised variant
+bool launch_conv_ring(const ConvArgs& a, int nt, int ncu, hipStream_t st); // + 3-stage patch ring, weights from L2; false = does not fit
 
 // ---- pre / post ------------------------------------------------------------------------------
 struct BaseTile

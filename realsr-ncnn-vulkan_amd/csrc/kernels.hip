@@ -734,6 +734,262 @@ void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st)
 #undef RSR_PIPE
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv3x3_ring: conv3x3_pipe with the activation patches in a THREE-deep LDS ring.
+// Measured on conv3x3_pipe (C2 frame): LDS-DMA fill alone ~65 ms, MFMA stream alone ~62 ms, together ~88 ms and
+// 113 ms with the epilogues -- one barrier per stage couples a loader with a single stage of lookahead to the MFMA
+// waves, so every epilogue (and every late DMA) stalls the other side.  Here the loaders run TWO patch stages
+// ahead with counted waits ("s_waitcnt vmcnt(P)": everything but my newest patch stage has landed); the weight
+// images stay double-buffered (they are small and always L2-hot).  Work-item descriptors are staged in LDS once per
+// launch so that no other vector load disturbs the loaders' counts.
+//   LDS: 3 x 39 KiB patches + 2 x 18 KiB weights (NT = 1) + bias + descriptors = ~157 KiB.  With 64 output
+//   channels the weight images are 36 KiB each and the ring no longer fits: launch_conv_ring() then returns false
+//   and the engine uses conv3x3_pipe.  (Reading the weight fragments straight from L2 instead -- tried -- costs
+//   4x the vector-memory traffic per workgroup and slowed the MFMA waves by 25-40 %.)
+// ---------------------------------------------------------------------------------------------
+constexpr int kRingDepth = 3;
+
+template <int NT, bool UPS, int EPI>
+__global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCW = 4 * NT;
+    constexpr int NTHREADS = (4 * NT + 4) * 64;
+    constexpr int WROWS = 9 * NT * 32;
+    constexpr int WBYTES = WROWS * 64;
+    constexpr int WITEMS = WROWS * 4;
+    constexpr int WPASS = (WITEMS + 255) / 256;
+    constexpr int WOFF = kRingDepth * kPatchLds;      // two weight images behind the patch ring
+    constexpr int BIAS_OFF = WOFF + 2 * WBYTES;
+    constexpr int ITEMS_OFF = BIAS_OFF + 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nplanes = a.n0 + a.n1;
+
+    const int per = (a.nitems + 7) >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    const int first = xcd * per + j;
+    const int end = min((xcd + 1) * per, a.nitems);
+    const int nmine = first < end ? (end - first + nj - 1) / nj : 0;
+    if (nmine == 0) return;
+    const int S = nmine * nplanes;
+
+    // stage this workgroup's work-item descriptors and the bias in LDS
+    {
+        uint4* dst = reinterpret_cast<uint4*>(smem + ITEMS_OFF);
+        const uint4* src = reinterpret_cast<const uint4*>(a.items);
+        for (int i = tid; i < nmine * 2; i += NTHREADS) dst[i] = src[(long long)(first + (i >> 1) * nj) * 2 + (i & 1)];
+        float* bl = reinterpret_cast<float*>(smem + BIAS_OFF);
+        if (tid < NT * 32) bl[tid] = a.bias[tid];
+    }
+    __syncthreads();
+    const WorkItem* items = reinterpret_cast<const WorkItem*>(smem + ITEMS_OFF);
+
+    if (wave >= NCW)
+    {
+        // ================= loader waves =================
+        // Stage t = patch P(t) in ring slot t%3 + weight image W(t) in weight buffer t&1.  P(t) may be issued once the
+        // MFMA waves are past stage t-3 (barrier B_{t-2}), W(t) once they are past stage t-2 (barrier B_{t-1}).  Issue
+        // order per loader wave:   W(0) P(0) P(1) | B_0 | W(1) P(2) | B_1 | W(2) P(3) | ...
+        // so before barrier B_s the newest NP instructions are exactly P(s+1) and "s_waitcnt vmcnt(NP)" means
+        // "P(s), W(s) and everything older have landed" (vector loads retire in order).
+        const int lw = wave - NCW, ltid = lw * 64 + lane;
+        const char* wbase = static_cast<const char*>(a.wpk) + (lw * 64 + lane) * 16;
+        auto issue_w = [&](int wck, int wsel) {
+            const char* wsrc = wbase + (long long)wck * WBYTES;
+            char* wb = smem + WOFF + wsel * WBYTES + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < WPASS; i++)
+                if (i * 256 + lw * 64 < WITEMS)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 4096),
+                                                     (__attribute__((address_space(3))) void*)(wb + i * 4096), 16, 0, 0);
+        };
+        auto wait_newest_patch_only_then_barrier = [&]() {
+            // 39 one-KiB patch pieces: loader waves 0-2 own 10 each, wave 3 owns 9
+            if (lw < 3) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+        };
+        issue_w(0, 0);
+        int t = 0, slot3 = 0, wck = 1 % nplanes; // wck = chunk of the next weight image to issue, W(t-1) at loop index t
+        for (int r = 0; r < nmine; r++)
+        {
+            const WorkItem it = items[r];
+            const int H = it.H, W = it.W, Wi = UPS ? (W >> 1) : W;
+            unsigned srcoff[kPatchIters]; // byte offset from (plane pixel 0 - kGuard); 0 = the plane's zero guard
+#pragma unroll
+            for (int i = 0; i < kPatchIters; i++)
+            {
+                const int jj = ltid + i * 256;
+                const int px = jj >> 2, sl = jj & 3;
+                const int rr = px / kPatchW, cc = px - rr * kPatchW;
+                const int gy = it.y0 - 1 + rr, gx = it.x0 - 1 + cc;
+                const bool ok = (jj < kPatchItems) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const int sy = UPS ? (gy >> 1) : gy, sx = UPS ? (gx >> 1) : gx;
+                srcoff[i] = ok ? unsigned(kGuard + (sy * Wi + sx) * 64 + ((sl ^ ((cc >> 2) & 3)) << 4)) : 0u;
+            }
+            for (int ck = 0; ck < nplanes; ck++, t++)
+            {
+                if (t >= 2)
+                {
+                    wait_newest_patch_only_then_barrier(); // B_{t-2}
+                    issue_w(wck, (t - 1) & 1);             // W(t-1)
+                    wck = (wck + 1 == nplanes) ? 0 : wck + 1;
+                }
+                char* buf = smem + slot3 * kPatchLds + lw * 1024;
+                slot3 = slot3 == kRingDepth - 1 ? 0 : slot3 + 1;
+                const char* gbase = ((ck < a.n0) ? plane_ptr(a.src0, it.slot, ck) : plane_ptr(a.src1, it.slot, ck - a.n0)) - kGuard;
+#pragma unroll
+                for (int i = 0; i < kPatchIters - 1; i++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
+                                                     (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
+                if (lw < 3)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
+                                                     (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
+            }
+        }
+        if (S >= 2)
+        {
+            wait_newest_patch_only_then_barrier(); // B_{S-2}
+            issue_w(wck, (S - 1) & 1);             // W(S-1)
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // B_{S-1}
+        return;
+    }
+
+    // ================= MFMA waves (identical arithmetic to conv3x3_pipe) =================
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int wrow = wave & 3, ntw = wave >> 2;
+    int xcol[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; dx++)
+    {
+        const int c = l32 + dx;
+        xcol[dx] = wrow * 4 * kPatchW * 64 + c * 64 + ((hi ^ ((c >> 2) & 3)) << 4);
+    }
+    const int woff = WOFF + (ntw * 32 + l32) * 64 + ((hi ^ ((l32 >> 2) & 3)) << 4);
+    const float* bias_lds = reinterpret_cast<const float*>(smem + BIAS_OFF);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[r][e] = 0.f;
+
+    int r = 0, ck = 0, slot3 = 0;
+    WorkItem it = items[0];
+    for (int s = 0; s < S; s++)
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // B_s: patch s and weights s are in LDS
+        const char* buf = smem + slot3 * kPatchLds;
+        const char* wb = smem + (s & 1) * WBYTES;
+        slot3 = slot3 == kRingDepth - 1 ? 0 : slot3 + 1;
+        if (!(a.dbg & 2))
+        {
+            half8 X0[6], X1[6], W0[3], W1[3];
+#define RSR_LOAD_STEP(X, Wf, T)                                                                                     \
+    {                                                                                                                \
+        constexpr int dx_ = (T) >> 1, cb_ = (T)&1;                                                                   \
+        _Pragma("unroll") for (int dy = 0; dy < 3; dy++)                                                             \
+        {                                                                                                            \
+            X[dy] = *reinterpret_cast<const half8*>(buf + ((xcol[dx_] ^ (cb_ << 5)) + dy * (kPatchW * 64)));         \
+            Wf[dy] = *reinterpret_cast<const half8*>(wb + ((woff ^ (cb_ << 5)) + (dy * 3 + dx_) * (NT * 32 * 64)));  \
+        }                                                                                                            \
+        _Pragma("unroll") for (int rr = 3; rr < 6; rr++)                                                             \
+            X[rr] = *reinterpret_cast<const half8*>(buf + ((xcol[dx_] ^ (cb_ << 5)) + rr * (kPatchW * 64)));         \
+    }
+#define RSR_MFMA_STEP(X, Wf)                                                                                         \
+    {                                                                                                                \
+        _Pragma("unroll") for (int dy = 0; dy < 3; dy++) _Pragma("unroll") for (int rr = 0; rr < 4; rr++)            \
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[dy], X[rr + dy], acc[rr], 0, 0, 0);                  \
+    }
+            RSR_LOAD_STEP(X0, W0, 0)
+            RSR_LOAD_STEP(X1, W1, 1)
+            RSR_MFMA_STEP(X0, W0)
+            RSR_LOAD_STEP(X0, W0, 2)
+            RSR_MFMA_STEP(X1, W1)
+            RSR_LOAD_STEP(X1, W1, 3)
+            RSR_MFMA_STEP(X0, W0)
+            RSR_LOAD_STEP(X0, W0, 4)
+            RSR_MFMA_STEP(X1, W1)
+            RSR_LOAD_STEP(X1, W1, 5)
+            RSR_MFMA_STEP(X0, W0)
+            RSR_MFMA_STEP(X1, W1)
+#undef RSR_LOAD_STEP
+#undef RSR_MFMA_STEP
+            __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++)
+            {
+                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
+        }
+        if (++ck == nplanes)
+        {
+            if (!(a.dbg & 4))
+            {
+                f32x4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(bias_lds + ntw * 32 + q * 8 + hi * 4);
+                if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+                else if (it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W)
+                    conv_epilogue_t<EPI, false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+                else
+                    conv_epilogue_t<EPI, true>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+            }
+            ck = 0;
+            r++;
+            if (r < nmine) it = items[r];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[rr][e] = 0.f;
+        }
+    }
+}
+
+template <int NT, bool UPS, int EPI>
+static bool launch_conv_ring_t(const ConvArgs& a, int ncu, hipStream_t st)
+{
+    int grid = ncu & ~7;
+    const int per = (a.nitems + 7) / 8;
+    if (per * 8 < grid) grid = per * 8;
+    const int nj = grid / 8, nmine_max = (per + nj - 1) / nj;
+    const size_t lds = size_t(kRingDepth) * kPatchLds + 2 * size_t(9 * NT * 32 * 64) + 256 + size_t(nmine_max) * sizeof(WorkItem);
+    if (lds > 160 * 1024) return false; // does not fit (64 output channels, or a very long descriptor list): use conv3x3_pipe
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring<NT, UPS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_ring<NT, UPS, EPI>), dim3(grid), dim3((4 * NT + 4) * 64), lds, st, a);
+    return true;
+}
+
+bool launch_conv_ring(const ConvArgs& a, int nt, int ncu, hipStream_t st)
+{
+    if (a.nitems <= 0) return true;
+    if (nt != 1) return false;
+    const bool ups = a.lvl_out != a.lvl_in;
+    int epi = 0;
+    if (a.out16.base && !a.out32a.base && !a.out32b.base && !a.out_planar3 && !(a.dbg & 16))
+    {
+        if (a.res1_kind == 0 && a.res2_kind == 0) epi = 1;
+        else if (a.res1_kind == 1 && (a.res2_kind == 0 || a.res2_kind == 1)) epi = 2;
+    }
+#define RSR_RING(UPS_) (epi == 1 ? launch_conv_ring_t<1, UPS_, 1>(a, ncu, st) : epi == 2 ? launch_conv_ring_t<1, UPS_, 2>(a, ncu, st) : launch_conv_ring_t<1, UPS_, 0>(a, ncu, st))
+    return ups ? RSR_RING(true) : RSR_RING(false);
+#undef RSR_RING
+}
+
 template <int NT, bool UPS, bool DMA>
 static void launch_conv_t(const ConvArgs& a, hipStream_t st)
 {

@@ -447,6 +447,7 @@ size_t packed_size(const Model& m)
         const size_t np = size_t((c.cin + 31) / 32), nt = size_t((c.cout + 31) / 32);
         off = align256(off + np * 9 * nt * 32 * 64);
         off = align256(off + nt * 32 * 4);
+        off = align256(off + np * 18 * nt * 1024); // fragment-major copy
     }
     return off;
 }
@@ -463,7 +464,7 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
     std::memset(base, 0, need);
     PackedHeader* H = reinterpret_cast<PackedHeader*>(base);
     H->magic = kPackedMagic;
-    H->version = 1;
+    H->version = 2;
     H->nconv = uint32_t(m.convs.size());
     H->total_bytes = need;
     PackedConv* T = reinterpret_cast<PackedConv*>(base + sizeof(PackedHeader));
@@ -505,6 +506,25 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
         float* B = reinterpret_cast<float*>(base + off);
         for (int n = 0; n < c.cout; n++) B[n] = c.bias[size_t(n)];
         off = align256(off + size_t(nt) * 32 * 4);
+        P.wf_off = off;
+        uint16_t* F = reinterpret_cast<uint16_t*>(base + off);
+        for (int ck = 0; ck < np; ck++)
+            for (int dx = 0; dx < 3; dx++)
+                for (int cb = 0; cb < 2; cb++)
+                    for (int dy = 0; dy < 3; dy++)
+                        for (int t = 0; t < nt; t++)
+                        {
+                            uint16_t* blk = F + ((((size_t(ck) * 3 + dx) * 2 + cb) * 3 + dy) * nt + t) * 512;
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int e8 = 0; e8 < 8; e8++)
+                                {
+                                    const int n = t * 32 + (lane & 31), ic = ck * 32 + cb * 16 + (lane >> 5) * 8 + e8;
+                                    float v = 0.f;
+                                    if (n < c.cout && ic < c.cin) v = c.weight[(size_t(n) * c.cin + ic) * 9 + dy * 3 + dx];
+                                    blk[lane * 8 + e8] = f32_to_f16(v);
+                                }
+                        }
+        off = align256(off + size_t(np) * 18 * nt * 1024);
     }
     return RSR_OK;
 }
@@ -517,14 +537,14 @@ int check_packed(const void* blob, size_t bytes, std::string& err)
         return RSR_E_FORMAT;
     }
     const PackedHeader* H = static_cast<const PackedHeader*>(blob);
-    if (H->magic != kPackedMagic || H->version != 1 || H->nconv != uint32_t(kNumConvs) || H->total_bytes != bytes)
+    if (H->magic != kPackedMagic || H->version != 2 || H->nconv != uint32_t(kNumConvs) || H->total_bytes != bytes)
     {
         err = "packed blob header mismatch";
         return RSR_E_FORMAT;
     }
     const PackedConv* T = reinterpret_cast<const PackedConv*>(static_cast<const unsigned char*>(blob) + sizeof(PackedHeader));
     for (uint32_t i = 0; i < H->nconv; i++)
-        if (T[i].w_off >= bytes || T[i].b_off >= bytes || T[i].nplanes == 0 || T[i].nt == 0 || T[i].nt > 2)
+        if (T[i].w_off >= bytes || T[i].b_off >= bytes || T[i].wf_off >= bytes || T[i].nplanes == 0 || T[i].nt == 0 || T[i].nt > 2)
         {
             err = "packed blob conv table corrupt";
             return RSR_E_FORMAT;

@@ -63,7 +63,7 @@ int load_model(const std::string& param, const std::string& bin, Model& m, std::
 struct PackedHeader
 {
     uint32_t magic;   // 'RSRP'
-    uint32_t version; // 1
+    uint32_t version; // 2
     uint32_t nconv;
     uint32_t reserved;
     uint64_t total_bytes;
@@ -76,6 +76,9 @@ struct PackedConv
     uint32_t nt;            // ceil(cout/32)
     float slope;
     uint64_t w_off, b_off;  // byte offsets from blob start (256-B aligned)
+    uint64_t wf_off;        // fragment-major copy of the weights (conv3x3_ring reads MFMA A-fragments straight from L2):
+                            // [chunk][dx 0..2][cb 0..1][dy 0..2][nt][lane 0..63][8 halfs]; lane = hi*32 + n holds
+                            // W[cout nt*32+n][cin chunk*32 + cb*16 + hi*8 .. +8][tap dy*3+dx] -> one coalesced 1 KiB per fragment
 };
 constexpr uint32_t kPackedMagic = 0x50525352u; // "RSRP"
 

@@ -34,8 +34,8 @@ def sec_conv(sr):
     rng = np.random.default_rng(0)
     cases = [(64, 32, 20, 40, False), (96, 32, 17, 33, False), (192, 64, 16, 32, False), (3, 64, 9, 70, False),
              (64, 3, 33, 31, False), (64, 64, 10, 21, True), (160, 32, 48, 64, False)]
-    for dma in (2, 1):
-        sr.set_option("kernel", 2 if dma == 2 else 1)
+    for dma in (3, 2):
+        sr.set_option("kernel", dma)
         sr.set_option("use_dma", 1)
         for cin, cout, h, w, ups in cases:
             x = rng.standard_normal((cin, h, w)).astype(np.float16)
@@ -54,7 +54,7 @@ def sec_conv(sr):
                     print("    per-channel max err (first 8):", np.abs(got - ref).reshape(cout, -1).max(1)[:8])
                     print("    per-row max err (first 8):", np.abs(got - ref).max(axis=(0, 2))[:8])
                     print("    per-col max err (first 8):", np.abs(got - ref).max(axis=(0, 1))[:8])
-    sr.set_option("kernel", 2)
+    sr.set_option("kernel", 3)
 
 
 def sec_shader(sr):

@@ -59,7 +59,7 @@ def test_conv3x3_layer_matches_oracle(sr, cin, cout, h, w, ups, lrelu):
         xr = xr.repeat(2, axis=1).repeat(2, axis=2)
     ref = oracle.conv3x3(xr, wt, b, 2 if lrelu else 0, 0.2)
     try:
-        for kernel, dma in ((2, 1), (1, 1), (1, 0)):  # conv3x3_pipe, conv3x3_mfma with LDS-DMA / register staging
+        for kernel, dma in ((3, 1), (2, 1), (1, 1), (1, 0)):  # conv3x3_ring, conv3x3_pipe, conv3x3_mfma with LDS-DMA / register staging
             sr.set_option("kernel", kernel)
             sr.set_option("use_dma", dma)
             got = sr.conv3x3(x, wt, b, lrelu=lrelu, upsample2x=ups).astype(np.float32)
@@ -67,7 +67,7 @@ def test_conv3x3_layer_matches_oracle(sr, cin, cout, h, w, ups, lrelu):
             assert (np.abs(got - ref) <= np.abs(ref) * 2.0 ** -10 + 1e-3).all(), "kernel=%d dma=%d max err %g" % (
                 kernel, dma, np.abs(got - ref).max())
     finally:
-        sr.set_option("kernel", 2)
+        sr.set_option("kernel", 3)
         sr.set_option("use_dma", 1)
 
 

@@ -93,12 +93,12 @@ def test_packed_blob_layout(model_dir, weights):
     """Un-swizzle the packed LDS images and compare with the OIHW weights."""
     blob = R.model_pack(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
     magic, version, nconv, _ = np.frombuffer(blob[:16], np.uint32)
-    assert magic == 0x50525352 and version == 1 and nconv == 351
+    assert magic == 0x50525352 and version == 2 and nconv == 351
     assert int(np.frombuffer(blob[16:24], np.uint64)[0]) == blob.size
     rec = np.dtype([("cin", "<u4"), ("cout", "<u4"), ("act", "<u4"), ("nplanes", "<u4"), ("nt", "<u4"),
-                    ("slope", "<f4"), ("w_off", "<u8"), ("b_off", "<u8")])
-    assert rec.itemsize == 40
-    table = np.frombuffer(blob[24:24 + 351 * 40], rec)
+                    ("slope", "<f4"), ("w_off", "<u8"), ("b_off", "<u8"), ("wf_off", "<u8")])
+    assert rec.itemsize == 48
+    table = np.frombuffer(blob[24:24 + 351 * 48], rec)
     specs = synth.conv_specs()
     for i in (0, 1, 4, 5, 346, 349, 350):
         t = table[i]
@@ -119,6 +119,11 @@ def test_packed_blob_layout(model_dir, weights):
                     got = img[ck, row, slot ^ swz].astype(np.float32)
                     want = Wp[n, ck * 32 + slot * 8: ck * 32 + slot * 8 + 8, tap // 3, tap % 3]
                     assert (got == want).all(), (i, ck, row, slot)
+        # fragment-major copy: [chunk][dx][cb][dy][nt][lane][8]
+        fr = np.frombuffer(blob[int(t["wf_off"]):int(t["wf_off"]) + np_ * 18 * nt * 1024], np.float16).reshape(np_, 3, 2, 3, nt, 64, 8)
+        for ck, dx, cb, dy, tt, lane in [(0, 0, 0, 0, 0, 0), (np_ - 1, 2, 1, 2, nt - 1, 63), (0, 1, 1, 2, 0, 37)]:
+            n, ic0 = tt * 32 + (lane & 31), ck * 32 + cb * 16 + (lane >> 5) * 8
+            assert (fr[ck, dx, cb, dy, tt, lane].astype(np.float32) == Wp[n, ic0:ic0 + 8, dy, dx]).all()
         bias = np.frombuffer(blob[int(t["b_off"]):int(t["b_off"]) + nt * 32 * 4], np.float32)
         assert (bias[:cout] == b).all() and (bias[cout:] == 0).all()
 

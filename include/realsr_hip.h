@@ -150,6 +150,10 @@ int rsr_get_profile(rsr_ctx* ctx, rsr_profile* out, int reset);
  * over the profiled calls since the last reset. */
 int rsr_get_conv_times(rsr_ctx* ctx, double* ms, int n, int reset);
 
+/* Profiling aid: after rsr_set_option("trace_conv", i) the launch of convolution i records, for workgroup 0 /
+ * MFMA wave 0, the s_memtime stamps (arrival at, release from) every stage barrier; n <= 1024 values. */
+int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
+
 /* Engine knobs (optional).  key/value:
  *   "max_workspace_mb"  tile-batch memory budget (default 65536)
  *   "trunk_fp32"        0 [default]: every feature tensor incl. the residual trunk is stored as fp16, like the

@@ -21,7 +21,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 EXPORTS = [
     "rsr_create", "rsr_destroy", "rsr_load", "rsr_set_params", "rsr_process", "rsr_process_device",
     "rsr_model_pack", "rsr_load_packed", "rsr_model_info", "rsr_preproc", "rsr_preproc_tta", "rsr_postproc",
-    "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times",
+    "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times", "rsr_get_trace",
     "rsr_set_option", "rsr_last_error", "rsr_version",
 ]
 
@@ -92,6 +92,7 @@ def lib():
     L.rsr_set_profiling.argtypes = [vp, ip]
     L.rsr_get_profile.argtypes = [vp, C.POINTER(Profile), ip]
     L.rsr_get_conv_times.argtypes = [vp, C.POINTER(C.c_double), ip, ip]
+    L.rsr_get_trace.argtypes = [vp, C.POINTER(C.c_ulonglong), ip]
     L.rsr_set_option.argtypes = [vp, cp, C.c_longlong]
     L.rsr_last_error.argtypes = [vp]
     L.rsr_last_error.restype = cp
@@ -257,6 +258,11 @@ class RealSR:
         arr = (C.c_double * 351)()
         self._ck(self._L.rsr_get_conv_times(self._h, arr, 351, int(bool(reset))))
         return np.array(arr[:])
+
+    def get_trace(self, n=1024):
+        arr = (C.c_ulonglong * n)()
+        self._ck(self._L.rsr_get_trace(self._h, arr, n))
+        return np.array(arr[:], dtype=np.uint64)
 
     def get_profile(self, reset=True):
         p = Profile()

@@ -291,6 +291,17 @@ int rsr_get_conv_times(rsr_ctx* ctx, double* ms, int n, int reset)
     return RSR_OK;
 }
 
+int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n)
+{
+    if (!ctx || !out || n < 0 || n > 1024) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    if (!ctx->e.trace_buf.p) return ctx->e.fail(RSR_E_STATE, "tracing was never enabled");
+    if (hipSetDevice(ctx->e.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(out, ctx->e.trace_buf.p, size_t(n) * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return ctx->e.fail(RSR_E_DEVICE, "trace readback failed");
+    return RSR_OK;
+}
+
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
 {
     if (!ctx || !key) return RSR_E_ARG;
@@ -313,6 +324,19 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     }
     else if (k == "ring_nt2")
         ctx->e.ring_nt2 = value != 0;
+    else if (k == "trace_conv")
+    {
+        ctx->e.trace_conv = int(value);
+        if (value >= 0 && !ctx->e.trace_buf.p)
+        {
+            if (hipSetDevice(ctx->e.device) != hipSuccess || hipMalloc(&ctx->e.trace_buf.p, 8192) != hipSuccess)
+                return ctx->e.fail(RSR_E_NOMEM, "trace buffer");
+            ctx->e.trace_buf.bytes = 8192;
+            (void)hipMemset(ctx->e.trace_buf.p, 0, 8192);
+        }
+    }
+    else if (k == "stagger")
+        ctx->e.stagger_unit = int(value);
     else if (k == "dbg")
         ctx->e.dbg = int(value);
     else if (k == "num_cu")

@@ -392,6 +392,8 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         a.dims = b.d_dims;
         a.zeros = zeros.p;
         a.dbg = dbg;
+        a.stagger = stagger_unit * int(c.nplanes + 2);
+        a.trace = (trace_conv == ci) ? static_cast<unsigned long long*>(trace_buf.p) : nullptr;
         a.s1 = a.s2 = 1.f;
         return a;
     };

@@ -58,6 +58,9 @@ struct Engine
     int num_cu = 256;
     bool ring_nt2 = false; // use conv3x3_ring also for 64-output-channel convs (slower there: 168-VGPR budget)
     int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
+    int stagger_unit = 0; // s_sleep units (64 cycles) per (chunk + 2) of start delay between workgroup phases
+    int trace_conv = -1; // conv index whose launch records s_memtime stamps into trace_buf (profiling only)
+    DevBuf trace_buf;
     long long max_workspace_mb = 65536;
     hipStream_t stream = nullptr;
 

@@ -70,6 +70,9 @@ struct ConvArgs
     int nitems;
     const TileDim* dims;
     const void* zeros; // >= 16 zero bytes in device memory (LDS-DMA source for out-of-image pixels)
+    unsigned long long* trace; // optional: block 0 / wave 0 writes per-stage s_memtime stamps (profiling aid), 2 x u64 per stage
+    int stagger;       // conv3x3_ring: workgroup j delays its start by (j & 3) * stagger * 64 cycles so that the epilogue (store)
+                       // bursts of the 256 lock-stepped workgroups do not all hit HBM at the same moment
     int dbg;           // ablation switches for profiling (conv3x3_pipe): 1 skip DMA, 2 skip MFMA, 4 skip epilogue, 8 coalesced epilogue
 };
 

@@ -190,6 +190,155 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& a, f32x16 (&acc)
     }
 }
 
+// EPI 1 through a private LDS transpose (conv3x3_ring).  s_memtime stamps showed the direct epilogue above costing
+// ~5,500 cycles per block although it is only ~250 instructions: its 16 stores per wave each scatter 64 x 8 B over 32
+// different 64-byte segments, i.e. 2,048 partial-line write requests per block leave the CU.  Here the finished
+// rows go through LDS so that every store instruction writes 16 whole pixels (1 KiB contiguous, 4 lanes x 16 B
+// per pixel): 512 requests per block, 8 store instructions per wave.
+// Scratch: the two patch rows of the stage just consumed that ONLY this wave reads (rows 4*wrow+2, +3 of the
+// 18-row patch; neighbours' halos stop at +1 / start at +4) -- free until the loaders refill the slot, which needs
+// the barrier this wave has not reached yet.  DS operations of one wave execute in order, so no barrier is needed.
+template <bool CHECK>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[4], const f32x4 (&bq)[4], int slot, int y0, int x0,
+                                                  int H, int W, int wrow, int lane, char* patch)
+{
+    const int l32 = lane & 31, hi = lane >> 5;
+    char* scratch = patch + (4 * wrow + 2) * (kPatchW * 64);
+    char* wr = scratch + l32 * 64 + hi * 8;
+    const int wswz = (l32 >> 1) & 3;
+    // read side: 16 pixels per instruction, lane -> (pixel = lane>>2, 16-byte piece = lane&3)
+    const int rpx = lane >> 2, rpiece = lane & 3;
+    const float slope = a.lrelu ? 0.2f : 1.f;
+    char* op = const_cast<char*>(plane_ptr(a.out16, slot, 0));
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+    {
+#pragma unroll
+        for (int rl = 0; rl < 2; rl++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    const float v = acc[half * 2 + rl][q * 4 + e] + bq[q][e];
+                    o[e] = (_Float16)fmaxf(v, v * slope);
+                }
+                *reinterpret_cast<half4*>(wr + rl * (32 * 64) + ((q ^ wswz) << 4)) = o;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int px = k * 16 + rpx, rl = px >> 5, col = px & 31;
+            const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * 64 + ((rpiece ^ ((col >> 1) & 3)) << 4));
+            const int y = y0 + wrow * 4 + half * 2 + rl, x = x0 + col;
+            if (!CHECK || (y < H && x < W)) *reinterpret_cast<uint4*>(op + ((long long)y * W + x) * 64 + rpiece * 16) = v;
+        }
+    }
+}
+
+// The same LDS transpose for workgroups with two MFMA waves per block row (NT = 2: waves (wrow, ntw=0/1) share the
+// patch rows, so each owns ONE private row: 4*wrow+2+ntw, 2176 B >= one 32-pixel x 32-channel row) and for the
+// residual epilogue EPI 2: the value staged in LDS is t = fp16(s1*(acc+b)); in the transposed domain every lane owns
+// 8 consecutive channels of a pixel, loads the residual(s) as one coalesced 16-byte piece and stores
+// fp16((t + r1)*s2 + r2).  (t is rounded once more than in the direct epilogue: <= 2^-11 * |0.2*x5|, a tenth of the
+// output's own fp16 ulp; the parity tests bound it.)  Residual planes are fetched before the LDS round trips.
+template <int EPI, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_lds_row(const ConvArgs& a, f32x16 (&acc)[4], const f32x4 (&bq)[4], int nt, int slot,
+                                                      int y0, int x0, int H, int W, int wrow, int lane, char* patch,
+                                                      volatile int* my_flag, volatile int* partner_flag, int epoch)
+{
+    // The scratch row is private with respect to the other row groups, but the partner wave (same rows, other 32
+    // output channels) reads it as MFMA operand: tell the partner that this wave's operand reads of the item are
+    // done (DS operations of a wave complete in order, so the flag write follows them), then wait for the partner.
+    if (partner_flag)
+    {
+        if (lane == 0) *my_flag = epoch;
+        while (*partner_flag < epoch) __builtin_amdgcn_s_sleep(1);
+    }
+    const int l32 = lane & 31, hi = lane >> 5;
+    char* scratch = patch + (4 * wrow + 2 + nt) * (kPatchW * 64);
+    char* wr = scratch + l32 * 64 + hi * 8;
+    const int wswz = (l32 >> 1) & 3;
+    const int rpx = lane >> 2, rpiece = lane & 3; // read side: 16 pixels per instruction
+    const float slope = a.lrelu ? 0.2f : 1.f;
+    char* op = const_cast<char*>(plane_ptr(a.out16, slot, nt));
+    const bool has2 = (EPI == 2) && a.res2_kind == 1;
+    const char* r1p = nullptr;
+    const char* r2p = nullptr;
+    half8 zero8;
+#pragma unroll
+    for (int e = 0; e < 8; e++) zero8[e] = (_Float16)0.f;
+    if (EPI == 2)
+    {
+        r1p = plane_ptr(a.res1, slot, nt);
+        r2p = has2 ? plane_ptr(a.res2, slot, nt) : r1p;
+    }
+    // residual fetch runs one row ahead of its use (16 + 8 registers instead of 64)
+    auto fetch = [&](const char* p, int rr, int k) -> half8 {
+        const int y = y0 + wrow * 4 + rr, x = x0 + k * 16 + rpx;
+        return (!CHECK || (y < H && x < W)) ? *reinterpret_cast<const half8*>(p + ((long long)y * W + x) * 64 + rpiece * 16) : zero8;
+    };
+    half8 r1n[2] = {zero8, zero8};
+    if (EPI == 2)
+    {
+        r1n[0] = fetch(r1p, 0, 0);
+        r1n[1] = fetch(r1p, 0, 1);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+    {
+        half8 r1c[2] = {r1n[0], r1n[1]};
+        half8 r2[2] = {zero8, zero8};
+        if (EPI == 2)
+        {
+            if (rr < 3)
+            {
+                r1n[0] = fetch(r1p, rr + 1, 0);
+                r1n[1] = fetch(r1p, rr + 1, 1);
+            }
+            if (has2)
+            {
+                r2[0] = fetch(r2p, rr, 0);
+                r2[1] = fetch(r2p, rr, 1);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                float v = acc[rr][q * 4 + e] + bq[q][e];
+                if (EPI == 1) v = fmaxf(v, v * slope);
+                else v = v * a.s1;
+                o[e] = (_Float16)v;
+            }
+            *reinterpret_cast<half4*>(wr + ((q ^ wswz) << 4)) = o;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const int col = k * 16 + rpx;
+            half8 t = *reinterpret_cast<const half8*>(scratch + col * 64 + ((rpiece ^ ((col >> 1) & 3)) << 4));
+            if (EPI == 2)
+            {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                {
+                    float v = (float)t[e] + (float)r1c[k][e];
+                    if (has2) v = v * a.s2 + (float)r2[k][e];
+                    t[e] = (_Float16)v;
+                }
+            }
+            const int y = y0 + wrow * 4 + rr, x = x0 + col;
+            if (!CHECK || (y < H && x < W)) *reinterpret_cast<half8*>(op + ((long long)y * W + x) * 64 + rpiece * 16) = t;
+        }
+    }
+}
+
 // DMA = true: both LDS images are filled by LDS-DMA (global_load_lds_dwordx4: per-lane global source,
 // wave-uniform LDS base + lane*16 destination), so staging costs no VGPRs and no ds_write; the XOR
 // swizzle is applied on the SOURCE address (LDS item i receives logical slot (i&3)^((i>>4)&3) of
@@ -444,7 +593,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
     // 1-KiB global stores.  The store path (and its texture-addresser time) leaves the MFMA waves' critical path.
     constexpr bool OUTBOX = (EPI == 3);
     static_assert(!OUTBOX || NT == 1, "outbox epilogue is built for NT == 1");
-    constexpr int OUTBOX_OFF = 2 * STAGE + 256;
+    constexpr int OUTBOX_OFF = 2 * STAGE + 256 + 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -573,6 +722,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
     // with 4 ds_read_b128 instead of pinning 16 VGPRs or paying a global-load latency per item
     float* bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE);
     if (tid < NT * 32) bias_lds[tid] = a.bias[tid];
+    if (tid < 16) reinterpret_cast<int*>(smem + 2 * STAGE + 256)[tid] = 0; // epilogue hand-shake flags (NT = 2)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the ds_write has landed before this wave's first barrier
 
     int r = 0, ck = 0;
@@ -585,7 +735,15 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
         // All this barrier must order is LDS: the DMA writes of stage s (drained by the loaders before they
         // arrive) against our ds_reads below, and our reads of stage s-1 (consumed by MFMAs already) against
         // the loaders' next fill.
+        unsigned long long t_arrive = 0;
+        const bool tracing = a.trace && blockIdx.x == 0 && wave == 0;
+        if (tracing) t_arrive = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // barrier B_s: stage s is in LDS (our outbox writes landed)
+        if (tracing && s < 512 && lane == 0)
+        {
+            a.trace[2 * s] = t_arrive;
+            a.trace[2 * s + 1] = __builtin_amdgcn_s_memtime();
+        }
         const char* buf = smem + (s & 1) * STAGE;
         if (!(a.dbg & 2))
         {
@@ -667,6 +825,16 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 }
                 else if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
                 else if (EPI == 3) {}
+                else if ((EPI == 1 || EPI == 2) && !(a.dbg & 64))
+                { // coalesced stores through a private LDS row of the patch that was just consumed
+                    volatile int* flags = reinterpret_cast<volatile int*>(smem + 2 * STAGE + 256);
+                    volatile int* mine = flags + wave;
+                    volatile int* partner = (NT == 2) ? flags + (wave ^ 4) : nullptr;
+                    if (it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W)
+                        conv_epilogue_lds_row<(EPI == 2 ? 2 : 1), false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf), mine, partner, r + 1);
+                    else
+                        conv_epilogue_lds_row<(EPI == 2 ? 2 : 1), true>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf), mine, partner, r + 1);
+                }
                 else if (it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W)
                     conv_epilogue_t<EPI, false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
                 else
@@ -688,7 +856,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
 template <int NT, bool UPS, int EPI>
 static void launch_conv_pipe_t(const ConvArgs& a, int ncu, hipStream_t st)
 {
-    const size_t lds = 2 * (size_t(kPatchLds) + size_t(9 * NT * 32 * 64)) + 256 + (EPI == 3 ? 32768 : 0); // two stages + bias (+ outbox)
+    const size_t lds = 2 * (size_t(kPatchLds) + size_t(9 * NT * 32 * 64)) + 256 + 64 + (EPI == 3 ? 32768 : 0); // two stages + bias + flags (+ outbox)
     static bool attr_set = false;
     if (!attr_set)
     {
@@ -879,9 +1047,18 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
 
     int r = 0, ck = 0, slot3 = 0;
     WorkItem it = items[0];
+    for (int k = (j & 3) * a.stagger; k > 0; k -= 64) __builtin_amdgcn_s_sleep(64); // de-phase the workgroups (see ConvArgs::stagger)
+    const bool tracing = a.trace && blockIdx.x == 0 && wave == 0;
     for (int s = 0; s < S; s++)
     {
+        unsigned long long t_arrive = 0;
+        if (tracing) t_arrive = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // B_s: patch s and weights s are in LDS
+        if (tracing && s < 512 && lane == 0)
+        {
+            a.trace[2 * s] = t_arrive;                         // arrival at barrier B_s
+            a.trace[2 * s + 1] = __builtin_amdgcn_s_memtime(); // release from barrier B_s
+        }
         const char* buf = smem + slot3 * kPatchLds;
         const char* wb = smem + (s & 1) * WBYTES;
         slot3 = slot3 == kRingDepth - 1 ? 0 : slot3 + 1;
@@ -938,8 +1115,14 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
                 f32x4 bq[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(bias_lds + ntw * 32 + q * 8 + hi * 4);
+                const bool interior = it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W;
                 if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
-                else if (it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W)
+                else if (EPI == 1 && NT == 1 && !(a.dbg & 64))
+                {
+                    if (interior) conv_epilogue_lds<false>(a, acc, bq, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf));
+                    else conv_epilogue_lds<true>(a, acc, bq, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf));
+                }
+                else if (interior)
                     conv_epilogue_t<EPI, false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
                 else
                     conv_epilogue_t<EPI, true>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);

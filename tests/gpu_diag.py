@@ -210,9 +210,42 @@ def main():
                 sec_e2e(net)
             elif s == "perf":
                 sec_perf()
+            elif s == "trace":
+                sec_trace()
         except Exception:
             traceback.print_exc()
             print("SECTION FAILED:", s, flush=True)
+
+
+
+
+def sec_trace():
+    """per-stage barrier stamps of workgroup 0 / MFMA wave 0 for a few conv launches (kernel 3, NT=1)"""
+    import torch  # noqa: F401
+    pp, bp = os.path.join(MODELS, "models-DF2K", "x4.param"), os.path.join(MODELS, "models-DF2K", "x4.bin")
+    sr = R.RealSR(0)
+    sr.load(pp, bp)
+    sr.tilesize = 200
+    img = synth.make_image(3, 1920, 1080)
+    sr.process(img)
+    for ci, name in [(1, "64->32"), (4, "160->32"), (5, "192->64")]:
+        sr.set_option("trace_conv", ci)
+        sr.process(img)
+        tr = sr.get_trace(1024).astype(np.int64).reshape(-1, 2)
+        n = int((tr[:, 0] > 0).sum())
+        tr = tr[:n]
+        arrive, release = tr[:, 0], tr[:, 1]
+        wait = release - arrive
+        busy = arrive[1:] - release[:-1]
+        nplanes = {1: 2, 4: 5, 5: 6}[ci]
+        print("  conv %d (%s): %d stages traced, total %d ticks" % (ci, name, n, release[-1] - arrive[0]))
+        print("    barrier wait ticks: mean %.0f  p50 %.0f  p90 %.0f  max %d" % (wait.mean(), np.median(wait), np.quantile(wait, 0.9), wait.max()))
+        last = (np.arange(n - 1) % nplanes) == nplanes - 1  # segments that contain an epilogue
+        print("    busy (release->next arrival): plain stages mean %.0f p50 %.0f | stages with epilogue mean %.0f p50 %.0f" % (
+            busy[~last].mean(), np.median(busy[~last]), busy[last].mean(), np.median(busy[last])))
+        print("    first 12 (wait,busy):", [(int(w), int(b)) for w, b in zip(wait[:12], busy[:12])])
+    sr.set_option("trace_conv", -1)
+    sr.close()
 
 
 if __name__ == "__main__":

@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librealsr_hip.so")
+# RSR_LIB: load an alternative build of the same library (kernel experiments: tools/build_variant.sh)
+LIB_PATH = os.environ.get("RSR_LIB") or os.path.join(_HERE, "lib", "librealsr_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTS = [

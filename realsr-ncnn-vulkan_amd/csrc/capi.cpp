@@ -293,7 +293,7 @@ int rsr_get_conv_times(rsr_ctx* ctx, double* ms, int n, int reset)
 
 int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n)
 {
-    if (!ctx || !out || n < 0 || n > 1024) return RSR_E_ARG;
+    if (!ctx || !out || n < 0 || n > 8192) return RSR_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->e.mu);
     if (!ctx->e.trace_buf.p) return ctx->e.fail(RSR_E_STATE, "tracing was never enabled");
     if (hipSetDevice(ctx->e.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
@@ -329,10 +329,10 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         ctx->e.trace_conv = int(value);
         if (value >= 0 && !ctx->e.trace_buf.p)
         {
-            if (hipSetDevice(ctx->e.device) != hipSuccess || hipMalloc(&ctx->e.trace_buf.p, 8192) != hipSuccess)
+            if (hipSetDevice(ctx->e.device) != hipSuccess || hipMalloc(&ctx->e.trace_buf.p, 65536) != hipSuccess)
                 return ctx->e.fail(RSR_E_NOMEM, "trace buffer");
-            ctx->e.trace_buf.bytes = 8192;
-            (void)hipMemset(ctx->e.trace_buf.p, 0, 8192);
+            ctx->e.trace_buf.bytes = 65536;
+            (void)hipMemset(ctx->e.trace_buf.p, 0, 65536);
         }
     }
     else if (k == "stagger")

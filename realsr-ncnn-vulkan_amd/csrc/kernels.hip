@@ -233,7 +233,14 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
             const int px = k * 16 + rpx, rl = px >> 5, col = px & 31;
             const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * 64 + ((rpiece ^ ((col >> 1) & 3)) << 4));
             const int y = y0 + wrow * 4 + half * 2 + rl, x = x0 + col;
-            if (!CHECK || (y < H && x < W)) *reinterpret_cast<uint4*>(op + ((long long)y * W + x) * 64 + rpiece * 16) = v;
+            if (!CHECK || (y < H && x < W))
+            {
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                u32x4* dstp = reinterpret_cast<u32x4*>(op + ((long long)y * W + x) * 64 + rpiece * 16);
+                const u32x4 vv = {v.x, v.y, v.z, v.w};
+                if (a.dbg & 256) __builtin_nontemporal_store(vv, dstp); // experiment: streaming stores
+                else *dstp = vv;
+            }
         }
     }
 }
@@ -334,7 +341,12 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvArgs& a, f32x16 
                 }
             }
             const int y = y0 + wrow * 4 + rr, x = x0 + col;
-            if (!CHECK || (y < H && x < W)) *reinterpret_cast<half8*>(op + ((long long)y * W + x) * 64 + rpiece * 16) = t;
+            if (!CHECK || (y < H && x < W))
+            {
+                half8* dstp = reinterpret_cast<half8*>(op + ((long long)y * W + x) * 64 + rpiece * 16);
+                if (a.dbg & 256) __builtin_nontemporal_store(t, dstp);
+                else *dstp = t;
+            }
         }
     }
 }
@@ -613,6 +625,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
     {
         // ================= loader waves =================
         const int lw = wave - NCW, ltid = lw * 64 + lane;
+        const bool nt_loads = a.dbg & 512; // experiment: non-temporal policy on the activation stream
                 const char* wbase = static_cast<const char*>(a.wpk);
         int t = 0;
         WorkItem nxt = a.items[first];
@@ -673,11 +686,19 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 {
 #pragma unroll
                     for (int i = 0; i < kPatchIters - 1; i++)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
-                                                         (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
+                        if (nt_loads)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
+                                                             (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 2);
+                        else
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
+                                                             (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
                     if (lw < 3) // the patch region is 39 one-KiB pieces: the last pass has only three
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
-                                                         (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
+                        if (nt_loads)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
+                                                             (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 2);
+                        else
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
+                                                             (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
 #pragma unroll
                     for (int i = 0; i < WPASS; i++)
                         if (i * 256 + lw * 64 < WITEMS)
@@ -964,6 +985,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
         // so before barrier B_s the newest NP instructions are exactly P(s+1) and "s_waitcnt vmcnt(NP)" means
         // "P(s), W(s) and everything older have landed" (vector loads retire in order).
         const int lw = wave - NCW, ltid = lw * 64 + lane;
+        const bool nt_loads = a.dbg & 512; // experiment: non-temporal policy on the activation stream
         const char* wbase = static_cast<const char*>(a.wpk) + (lw * 64 + lane) * 16;
         auto issue_w = [&](int wck, int wsel) {
             const char* wsrc = wbase + (long long)wck * WBYTES;
@@ -1010,11 +1032,19 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
                 const char* gbase = ((ck < a.n0) ? plane_ptr(a.src0, it.slot, ck) : plane_ptr(a.src1, it.slot, ck - a.n0)) - kGuard;
 #pragma unroll
                 for (int i = 0; i < kPatchIters - 1; i++)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
-                                                     (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
+                    if (nt_loads)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
+                                                         (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 2);
+                    else
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
+                                                         (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
                 if (lw < 3)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
-                                                     (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
+                    if (nt_loads)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
+                                                         (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 2);
+                    else
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
+                                                         (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
             }
         }
         if (S >= 2)
@@ -1039,32 +1069,64 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
     const int woff = WOFF + (ntw * 32 + l32) * 64 + ((hi ^ ((l32 >> 2) & 3)) << 4);
     const float* bias_lds = reinterpret_cast<const float*>(smem + BIAS_OFF);
 
+    // OVL: the act-only epilogue of the NT = 1 convs (276 of the 351) is folded into the LAST stage of its block.  The
+    // final 24 MFMAs run row-major (rows of the wave's 4x32-pixel tile finish 6 MFMAs apart) and each finished row goes
+    // bias -> LeakyReLU -> fp16 -> private LDS row (transpose) -> one coalesced 16-B/lane buffer store per 16 pixels
+    // while the matrix pipe works on the following rows; everything is branch-free (out-of-image lanes / rows are
+    // dropped by the buffer resource's range check) so the whole stage stays one scheduling region.  s_memtime stamps
+    // had the in-line epilogue at ~2,700 of the ~8,500 cycles of a 64->32 block.
+    constexpr bool OVL = (EPI == 1 && NT == 1);
     f32x16 acc[4];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[r][e] = 0.f;
+    f32x4 bqv[4]; // bias in accumulator layout, resident for the whole kernel in the OVL variant
+#pragma unroll
+    for (int q = 0; q < 4; q++) bqv[q] = *reinterpret_cast<const f32x4*>(bias_lds + ntw * 32 + q * 8 + hi * 4);
+    // transpose scratch = the two patch rows only this wave reads (4*wrow+2, +3), see conv_epilogue_lds
+    const int rpx = lane >> 2, rpiece = lane & 3;
+    const int scr_w = (4 * wrow + 2) * (kPatchW * 64) + l32 * 64 + hi * 8;
+    const int wswz = (l32 >> 1) & 3;
+    int scr_r[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+    {
+        const int col = k * 16 + rpx;
+        scr_r[k] = (4 * wrow + 2) * (kPatchW * 64) + col * 64 + ((rpiece ^ ((col >> 1) & 3)) << 4);
+    }
+    const float slope = a.lrelu ? 0.2f : 1.f;
+    const bool ovl = OVL && nplanes >= 2 && !(a.dbg & 64);
+    // +inf the compiler cannot see through: med3(v, slope*v, +inf) = max(v, slope*v) stays ONE v_med3_f32; with a literal it
+    // is folded to maxnum, which canonicalises the MFMA result first (one more v_max per value)
+    float pinf = __builtin_inff();
+    asm volatile("" : "+s"(pinf));
+#ifdef RSR_EXP_VALU
+    float exp_d[4] = {1.f, 2.f, 3.f, 4.f};
+    asm volatile("" : "+v"(exp_d[0]), "+v"(exp_d[1]), "+v"(exp_d[2]), "+v"(exp_d[3]));
+#endif
+    half8 zfrag;
+    {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 z = {0u, 0u, 0u, 0u};
+        asm volatile("" : "+v"(z));
+        zfrag = __builtin_bit_cast(half8, z);
+    }
+    f32x16 bias16; // the bias in accumulator layout: C operand of the re-initialising MFMA
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) bias16[q * 4 + e] = bqv[q][e];
+    if (ovl)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = bias16;
+    }
 
     int r = 0, ck = 0, slot3 = 0;
     WorkItem it = items[0];
     for (int k = (j & 3) * a.stagger; k > 0; k -= 64) __builtin_amdgcn_s_sleep(64); // de-phase the workgroups (see ConvArgs::stagger)
     const bool tracing = a.trace && blockIdx.x == 0 && wave == 0;
-    for (int s = 0; s < S; s++)
-    {
-        unsigned long long t_arrive = 0;
-        if (tracing) t_arrive = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // B_s: patch s and weights s are in LDS
-        if (tracing && s < 512 && lane == 0)
-        {
-            a.trace[2 * s] = t_arrive;                         // arrival at barrier B_s
-            a.trace[2 * s + 1] = __builtin_amdgcn_s_memtime(); // release from barrier B_s
-        }
-        const char* buf = smem + slot3 * kPatchLds;
-        const char* wb = smem + (s & 1) * WBYTES;
-        slot3 = slot3 == kRingDepth - 1 ? 0 : slot3 + 1;
-        if (!(a.dbg & 2))
-        {
-            half8 X0[6], X1[6], W0[3], W1[3];
 #define RSR_LOAD_STEP(X, Wf, T)                                                                                     \
     {                                                                                                                \
         constexpr int dx_ = (T) >> 1, cb_ = (T)&1;                                                                   \
@@ -1081,61 +1143,285 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
         _Pragma("unroll") for (int dy = 0; dy < 3; dy++) _Pragma("unroll") for (int rr = 0; rr < 4; rr++)            \
             acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[dy], X[rr + dy], acc[rr], 0, 0, 0);                  \
     }
-            RSR_LOAD_STEP(X0, W0, 0)
-            RSR_LOAD_STEP(X1, W1, 1)
-            RSR_MFMA_STEP(X0, W0)
-            RSR_LOAD_STEP(X0, W0, 2)
-            RSR_MFMA_STEP(X1, W1)
-            RSR_LOAD_STEP(X1, W1, 3)
-            RSR_MFMA_STEP(X0, W0)
-            RSR_LOAD_STEP(X0, W0, 4)
-            RSR_MFMA_STEP(X1, W1)
-            RSR_LOAD_STEP(X1, W1, 5)
-            RSR_MFMA_STEP(X0, W0)
-            RSR_MFMA_STEP(X1, W1)
-#undef RSR_LOAD_STEP
-#undef RSR_MFMA_STEP
-            __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
-#pragma unroll
-            for (int tt = 0; tt < 4; tt++)
+#ifdef RSR_EXP_OVLTRACE // experiment build: s_memtime stamps at the window boundaries of the overlapped-epilogue stage
+    unsigned long long ovl_ts[6];
+#define RSR_STAMP(K)                                                                                                 \
+    ovl_ts[K] = __builtin_amdgcn_s_memtime();                                                                        \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define RSR_STAMP(K)
+#endif
+#define RSR_MAIN_SCHED()                                                                                             \
+    {                                                                                                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);                                                          \
+        _Pragma("unroll") for (int tt = 0; tt < 4; tt++)                                                             \
+        {                                                                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);                                                       \
+        }                                                                                                            \
+    }
+// one MFMA then VALU work, six times: the interleave of a finishing row with the previous row's epilogue arithmetic
+#define RSR_ROW_SCHED()                                                                                              \
+    {                                                                                                                \
+        _Pragma("unroll") for (int m = 0; m < 6; m++)                                                                \
+        {                                                                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);                                                         \
+        }                                                                                                            \
+    }
+// the last two (dx, cb) steps of one output row: 6 dependent MFMAs
+#define RSR_MFMA_ROW(RR)                                                                                             \
+    {                                                                                                                \
+        _Pragma("unroll") for (int dy = 0; dy < 3; dy++)                                                             \
+            acc[RR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W0[dy], X0[(RR) + dy], acc[RR], 0, 0, 0);               \
+        _Pragma("unroll") for (int dy = 0; dy < 3; dy++)                                                             \
+            acc[RR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W1[dy], X1[(RR) + dy], acc[RR], 0, 0, 0);               \
+    }
+// finished row RR (the bias is already in the accumulator, see RSR_ROW_CLEAR): LeakyReLU = max(v, slope*v), fp16,
+// transpose-write into scratch row (RR & 1)
+#define RSR_ROW_TO_LDS(RR)                                                                                           \
+    {                                                                                                                \
+        char* wr_ = sbuf + scr_w + ((RR)&1) * (kPatchW * 64);                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                \
+        {                                                                                                            \
+            typedef float f32x2 __attribute__((ext_vector_type(2)));                                                 \
+            const f32x2 v01 = {acc[RR][q * 4 + 0], acc[RR][q * 4 + 1]}, v23 = {acc[RR][q * 4 + 2], acc[RR][q * 4 + 3]};         \
+            const f32x2 s01 = v01 * slope, s23 = v23 * slope;                                                        \
+            half4 o;                                                                                                 \
+            o[0] = (_Float16)__builtin_amdgcn_fmed3f(v01[0], s01[0], pinf);                              \
+            o[1] = (_Float16)__builtin_amdgcn_fmed3f(v01[1], s01[1], pinf);                              \
+            o[2] = (_Float16)__builtin_amdgcn_fmed3f(v23[0], s23[0], pinf);                              \
+            o[3] = (_Float16)__builtin_amdgcn_fmed3f(v23[1], s23[1], pinf);                              \
+            *reinterpret_cast<half4*>(wr_ + ((q ^ wswz) << 4)) = o;                                                  \
+        }                                                                                                            \
+    }
+// re-initialise a consumed accumulator row to the BIAS on the matrix pipe (0 x 0 + bias; the zero fragment is opaque to
+// the compiler): 64 v_mov per block would otherwise sit, unhidden, at the end of the stage, and the bias add leaves the
+// epilogue arithmetic
+#define RSR_ROW_CLEAR(RR)                                                                                            \
+    {                                                                                                                \
+        asm volatile("" : "+v"(zfrag)); /* a 'new' value each time, or the four clears are CSE'd into one + 48 v_mov */ \
+        acc[RR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zfrag, zfrag, bias16, 0, 0, 0);                             \
+    }
+#define RSR_ROW_FROM_LDS(RR, T)                                                                                      \
+    {                                                                                                                \
+        _Pragma("unroll") for (int k = 0; k < 2; k++)                                                                \
+            T[k] = *reinterpret_cast<const u32x4*>(sbuf + scr_r[k] + ((RR)&1) * (kPatchW * 64));                     \
+    }
+#define RSR_ROW_STORE(RR, T)                                                                                         \
+    {                                                                                                                \
+        const int y_ = it.y0 + wrow * 4 + (RR);                                                                      \
+        _Pragma("unroll") for (int k = 0; k < 2; k++)                                                                \
+            __builtin_amdgcn_raw_buffer_store_b128(T[k], y_ < it.H ? rs : rs0, voff[k], y_ * rowb, 0);               \
+    }
+    for (int s = 0; s < S; s++)
+    {
+        unsigned long long t_arrive = 0;
+        if (tracing) t_arrive = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // B_s: patch s and weights s are in LDS
+        if (tracing && s < 512 && lane == 0)
+        {
+            a.trace[2 * s] = t_arrive;                         // arrival at barrier B_s
+            a.trace[2 * s + 1] = __builtin_amdgcn_s_memtime(); // release from barrier B_s
+        }
+        const char* buf = smem + slot3 * kPatchLds;
+        const char* wb = smem + (s & 1) * WBYTES;
+        slot3 = slot3 == kRingDepth - 1 ? 0 : slot3 + 1;
+        if (!(a.dbg & 2))
+        {
+            half8 X0[6], X1[6], W0[3], W1[3];
+            if (ovl && ck == nplanes - 1)
             {
-                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                char* sbuf = const_cast<char*>(buf);
+                char* obase = const_cast<char*>(plane_ptr(a.out16, it.slot, 0));
+                const int rowb = it.W * 64;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (a.dbg & 4) ? 0 : it.H * rowb, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0, 0x00020000);
+                int voff[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                {
+                    const int x = it.x0 + k * 16 + rpx;
+                    voff[k] = x < it.W ? x * 64 + rpiece * 16 : int(0x80000000u);
+                }
+                u32x4 t0[2], t1[2], t2[2];
+                RSR_LOAD_STEP(X0, W0, 0)
+                RSR_LOAD_STEP(X1, W1, 1)
+                RSR_MFMA_STEP(X0, W0)
+                RSR_LOAD_STEP(X0, W0, 2)
+                RSR_MFMA_STEP(X1, W1)
+                RSR_LOAD_STEP(X1, W1, 3)
+                RSR_MFMA_STEP(X0, W0)
+                RSR_LOAD_STEP(X0, W0, 4)
+                RSR_MFMA_STEP(X1, W1)
+                RSR_LOAD_STEP(X1, W1, 5)
+                RSR_MAIN_SCHED()
+                __builtin_amdgcn_sched_barrier(0);
+                RSR_STAMP(0)
+                RSR_MFMA_ROW(0)
+                __builtin_amdgcn_sched_barrier(0);
+                RSR_STAMP(1)
+                RSR_MFMA_ROW(1) // || row 0: arithmetic, transpose-write
+                RSR_ROW_TO_LDS(0)
+                RSR_ROW_SCHED()
+                __builtin_amdgcn_sched_barrier(0);
+                RSR_STAMP(2)
+                RSR_MFMA_ROW(2) // || row 0: transpose-read; row 1: arithmetic, transpose-write
+                RSR_ROW_CLEAR(0)
+                RSR_ROW_FROM_LDS(0, t0)
+                RSR_ROW_TO_LDS(1)
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 9, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                _Pragma("unroll") for (int m = 0; m < 6; m++)
+                {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 7, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                RSR_STAMP(3)
+                RSR_MFMA_ROW(3) // || row 0: store; row 1: transpose-read; row 2: arithmetic, transpose-write
+                RSR_ROW_CLEAR(1)
+                RSR_ROW_STORE(0, t0)
+                RSR_ROW_FROM_LDS(1, t1)
+                RSR_ROW_TO_LDS(2)
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x40, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 9, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                _Pragma("unroll") for (int m = 0; m < 6; m++)
+                {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                RSR_STAMP(4)
+                // exposed tail: the operand fragments are dead here, so there are registers for two more rows in flight
+                RSR_ROW_FROM_LDS(2, t2)
+                RSR_ROW_TO_LDS(3)
+                RSR_ROW_FROM_LDS(3, t0)
+                RSR_ROW_STORE(1, t1)
+                RSR_ROW_CLEAR(2)
+                RSR_ROW_CLEAR(3)
+                RSR_ROW_STORE(2, t2)
+                RSR_ROW_STORE(3, t0)
+#ifdef RSR_EXP_OVLTRACE
+                __builtin_amdgcn_sched_barrier(0);
+                RSR_STAMP(5)
+                if (tracing && s < 512 && lane == 0)
+                {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) a.trace[1024 + 8 * s + k] = ovl_ts[k];
+                }
+#endif
             }
-            __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
+            else
+            {
+                RSR_LOAD_STEP(X0, W0, 0)
+                RSR_LOAD_STEP(X1, W1, 1)
+                RSR_MFMA_STEP(X0, W0)
+                RSR_LOAD_STEP(X0, W0, 2)
+                RSR_MFMA_STEP(X1, W1)
+                RSR_LOAD_STEP(X1, W1, 3)
+                RSR_MFMA_STEP(X0, W0)
+                RSR_LOAD_STEP(X0, W0, 4)
+                RSR_MFMA_STEP(X1, W1)
+                RSR_LOAD_STEP(X1, W1, 5)
+#ifdef RSR_EXP_PLAIN_ROWMAJOR // experiment: cost of six back-to-back dependent MFMAs
+                RSR_MAIN_SCHED()
+                __builtin_amdgcn_sched_barrier(0);
+                RSR_MFMA_ROW(0)
+                RSR_MFMA_ROW(1)
+                RSR_MFMA_ROW(2)
+                RSR_MFMA_ROW(3)
+#else
+                RSR_MFMA_STEP(X0, W0)
+                RSR_MFMA_STEP(X1, W1)
+#ifdef RSR_EXP_VALU // experiment: RSR_EXP_VALU independent VALU instructions per MFMA in the plain stage -- do they co-issue?
+#pragma unroll
+                for (int k = 0; k < 72 * RSR_EXP_VALU / 4; k++)
+                {
+                    exp_d[0] = __builtin_amdgcn_fmed3f(exp_d[0], slope, pinf);
+                    exp_d[1] = __builtin_amdgcn_fmed3f(exp_d[1], slope, pinf);
+                    exp_d[2] = __builtin_amdgcn_fmed3f(exp_d[2], slope, pinf);
+                    exp_d[3] = __builtin_amdgcn_fmed3f(exp_d[3], slope, pinf);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
+#pragma unroll
+                for (int tt = 0; tt < 4; tt++)
+                {
+#pragma unroll
+                    for (int g = 0; g < 3; g++)
+                    {
+#pragma unroll
+                        for (int m = 0; m < 4; m++)
+                        {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, RSR_EXP_VALU, 0);
+                        }
+                        if (g < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 24; m++)
+                {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, RSR_EXP_VALU, 0);
+                }
+#else
+                RSR_MAIN_SCHED()
+                __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
+#endif
+#endif
+            }
         }
         if (++ck == nplanes)
         {
-            if (!(a.dbg & 4))
+            if (!ovl)
             {
-                f32x4 bq[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(bias_lds + ntw * 32 + q * 8 + hi * 4);
-                const bool interior = it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W;
-                if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
-                else if (EPI == 1 && NT == 1 && !(a.dbg & 64))
+                if (!(a.dbg & 4))
                 {
-                    if (interior) conv_epilogue_lds<false>(a, acc, bq, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf));
-                    else conv_epilogue_lds<true>(a, acc, bq, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf));
+                    const bool interior = it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W;
+                    if (EPI == 0) conv_epilogue(a, acc, bqv, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+                    else if (EPI == 1 && NT == 1)
+                    {
+                        if (interior) conv_epilogue_lds<false>(a, acc, bqv, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf));
+                        else conv_epilogue_lds<true>(a, acc, bqv, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf));
+                    }
+                    else if (interior)
+                        conv_epilogue_t<EPI, false>(a, acc, bqv, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+                    else
+                        conv_epilogue_t<EPI, true>(a, acc, bqv, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
                 }
-                else if (interior)
-                    conv_epilogue_t<EPI, false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
-                else
-                    conv_epilogue_t<EPI, true>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[rr][e] = 0.f;
             }
             ck = 0;
             r++;
             if (r < nmine) it = items[r];
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[rr][e] = 0.f;
         }
     }
+#ifdef RSR_EXP_VALU
+    if (exp_d[0] + exp_d[1] + exp_d[2] + exp_d[3] == 12345.678f) a.trace[0] = 1;
+#endif
+#undef RSR_LOAD_STEP
+#undef RSR_MFMA_STEP
+#undef RSR_MFMA_ROW
+#undef RSR_MAIN_SCHED
+#undef RSR_STAMP
+#undef RSR_ROW_SCHED
+#undef RSR_ROW_TO_LDS
+#undef RSR_ROW_CLEAR
+#undef RSR_ROW_FROM_LDS
+#undef RSR_ROW_STORE
 }
 
 template <int NT, bool UPS, int EPI>

@@ -244,6 +244,18 @@ def sec_trace():
         print("    busy (release->next arrival): plain stages mean %.0f p50 %.0f | stages with epilogue mean %.0f p50 %.0f" % (
             busy[~last].mean(), np.median(busy[~last]), busy[last].mean(), np.median(busy[last])))
         print("    first 12 (wait,busy):", [(int(w), int(b)) for w, b in zip(wait[:12], busy[:12])])
+        if os.environ.get("RSR_OVLTRACE") and ci != 5:
+            full = sr.get_trace(8192).astype(np.int64)
+            ws = full[1024:1024 + 8 * n].reshape(n, 8)[:, :6]
+            rows = []
+            for s_ in range(n):
+                if ws[s_, 0] > 0:
+                    rows.append([ws[s_, 0] - release[s_]] + [ws[s_, k + 1] - ws[s_, k] for k in range(5)] +
+                                [(arrive[s_ + 1] - ws[s_, 5]) if s_ + 1 < n else 0])
+            rows = np.array(rows)
+            print("    overlapped-epilogue stage, ticks (median over %d): main48 %d | row0 %d | row1||E0 %d | row2||E1 %d | row3||E2 %d | tail %d | to-barrier %d" % (
+                (len(rows),) + tuple(int(np.median(rows[:, k])) for k in range(7))))
+            print("      p90:", [int(np.quantile(rows[:, k], 0.9)) for k in range(7)])
     sr.set_option("trace_conv", -1)
     sr.close()
 

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc csv output (counter_collection.csv) per kernel name: mean counter value per dispatch.
-   python tools/pmc_summary.py gpurun_out/<tag>"""
+   python tools/pmc_summary.py gpurun_out/<tag> [more dirs]"""
 import csv
 import glob
 import sys
 from collections import defaultdict
 
-root = sys.argv[1]
-for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
+files = []
+for root in sys.argv[1:]:
+    files += sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
+for f in files:
     acc = defaultdict(lambda: [0, 0.0])
     with open(f) as fh:
         for row in csv.DictReader(fh):

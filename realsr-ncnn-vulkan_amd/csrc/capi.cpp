@@ -332,7 +332,12 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
             if (hipSetDevice(ctx->e.device) != hipSuccess || hipMalloc(&ctx->e.trace_buf.p, 65536) != hipSuccess)
                 return ctx->e.fail(RSR_E_NOMEM, "trace buffer");
             ctx->e.trace_buf.bytes = 65536;
-            (void)hipMemset(ctx->e.trace_buf.p, 0, 65536);
+        }
+        if (value >= 0)
+        { // stamps of an earlier traced conv must not survive into this one's read-out
+            if (hipSetDevice(ctx->e.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemset(ctx->e.trace_buf.p, 0, 65536) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+                return ctx->e.fail(RSR_E_DEVICE, "trace buffer clear");
         }
     }
     else if (k == "stagger")

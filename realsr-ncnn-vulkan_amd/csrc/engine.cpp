@@ -437,7 +437,7 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         a.src1 = rdb_d(bi, 0); a.n1 = 4;
         a.s1 = 0.2f;
         if (trunk_fp32) { a.res1 = t32; a.res1_kind = 2; a.out32a = t32; }
-        else { a.res1 = xs; a.res1_kind = 1; }
+        else { a.res1 = xs; a.res1_kind = 1; a.res1_in_acc = !(dbg & 4096); a.res1_coef = 5.f; } // 1/0.2, exact in fp16
         if (bi == 2)
         {
             a.s2 = 0.2f;

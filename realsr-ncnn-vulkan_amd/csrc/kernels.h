@@ -58,6 +58,8 @@ struct ConvArgs
     PlaneSrc res1, res2;
     int res1_kind, res2_kind; // 0 none, 1 fp16 planes, 2 fp32 planes
     float s1, s2;
+    int res1_in_acc;  // res1 == input planes 0,1 of this conv (fp16): conv3x3_pipe<2,*,2> adds it as an identity tap, coefficient
+    float res1_coef;  // 1/s1 (must be exact in fp16); kernels that ignore the flag still read res1
     // outputs (any may be null)
     PlaneSrc out16;  // fp16 planes (NT planes)
     PlaneSrc out32a; // fp32 planes

@@ -251,19 +251,34 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
 // 8 consecutive channels of a pixel, loads the residual(s) as one coalesced 16-byte piece and stores
 // fp16((t + r1)*s2 + r2).  (t is rounded once more than in the direct epilogue: <= 2^-11 * |0.2*x5|, a tenth of the
 // output's own fp16 ulp; the parity tests bound it.)  Residual planes are fetched before the LDS round trips.
+typedef __attribute__((address_space(3))) int lds_int_t;
 template <int EPI, bool CHECK>
 __device__ __forceinline__ void conv_epilogue_lds_row(const ConvArgs& a, f32x16 (&acc)[4], const f32x4 (&bq)[4], int nt, int slot,
                                                       int y0, int x0, int H, int W, int wrow, int lane, char* patch,
-                                                      volatile int* my_flag, volatile int* partner_flag, int epoch)
+                                                      char* my_flag, char* partner_flag, int epoch, bool skip_r1,
+                                                      unsigned long long* ts = nullptr)
 {
+#ifdef RSR_EXP_OVLTRACE
+#define RSR_ETS(K) if (ts) ts[K] = __builtin_amdgcn_s_memtime();
+#else
+#define RSR_ETS(K)
+#endif
+    RSR_ETS(0)
     // The scratch row is private with respect to the other row groups, but the partner wave (same rows, other 32
     // output channels) reads it as MFMA operand: tell the partner that this wave's operand reads of the item are
     // done (DS operations of a wave complete in order, so the flag write follows them), then wait for the partner.
+    // The flags are accessed through explicit LDS pointers: a volatile access through a generic pointer becomes a
+    // FLAT load behind "s_waitcnt vmcnt(0)", i.e. it waits for the previous block's stores to be acknowledged.
     if (partner_flag)
     {
-        if (lane == 0) *my_flag = epoch;
-        while (*partner_flag < epoch) __builtin_amdgcn_s_sleep(1);
+        if (lane == 0) *(volatile lds_int_t*)my_flag = epoch;
+        while (*(volatile lds_int_t*)partner_flag < epoch) __builtin_amdgcn_s_sleep(1);
     }
+    RSR_ETS(1)
+    // The lane-derived addresses below are loop invariants of the kernel; hipcc hoists them out of the block loop and
+    // then SPILLS them (the MFMA loop needs every register; one scratch reload costs ~2.5 us per block here) --
+    // recompute them from an opaque copy of the lane id.
+    asm volatile("" : "+v"(lane));
     const int l32 = lane & 31, hi = lane >> 5;
     char* scratch = patch + (4 * wrow + 2 + nt) * (kPatchW * 64);
     char* wr = scratch + l32 * 64 + hi * 8;
@@ -287,8 +302,10 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvArgs& a, f32x16 
         const int y = y0 + wrow * 4 + rr, x = x0 + k * 16 + rpx;
         return (!CHECK || (y < H && x < W)) ? *reinterpret_cast<const half8*>(p + ((long long)y * W + x) * 64 + rpiece * 16) : zero8;
     };
+    // skip_r1: the first residual is already inside the accumulator (identity tap, see conv3x3_pipe) -- no fetch, no add
+    const bool has1 = (EPI == 2) && !skip_r1;
     half8 r1n[2] = {zero8, zero8};
-    if (EPI == 2)
+    if (has1)
     {
         r1n[0] = fetch(r1p, 0, 0);
         r1n[1] = fetch(r1p, 0, 1);
@@ -300,7 +317,7 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvArgs& a, f32x16 
         half8 r2[2] = {zero8, zero8};
         if (EPI == 2)
         {
-            if (rr < 3)
+            if (has1 && rr < 3)
             {
                 r1n[0] = fetch(r1p, rr + 1, 0);
                 r1n[1] = fetch(r1p, rr + 1, 1);
@@ -330,12 +347,13 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvArgs& a, f32x16 
         {
             const int col = k * 16 + rpx;
             half8 t = *reinterpret_cast<const half8*>(scratch + col * 64 + ((rpiece ^ ((col >> 1) & 3)) << 4));
-            if (EPI == 2)
+            if (EPI == 2 && (has1 || has2))
             {
 #pragma unroll
                 for (int e = 0; e < 8; e++)
                 {
-                    float v = (float)t[e] + (float)r1c[k][e];
+                    float v = (float)t[e];
+                    if (has1) v += (float)r1c[k][e];
                     if (has2) v = v * a.s2 + (float)r2[k][e];
                     t[e] = (_Float16)v;
                 }
@@ -348,7 +366,9 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvArgs& a, f32x16 
                 else *dstp = t;
             }
         }
+        RSR_ETS(2 + rr)
     }
+#undef RSR_ETS
 }
 
 // DMA = true: both LDS images are filled by LDS-DMA (global_load_lds_dwordx4: per-lane global source,
@@ -684,6 +704,8 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 const char* wsrc = wbase + (long long)ck * (WROWS * 64) + (lw * 64 + lane) * 16;
                 if (!(a.dbg & 1))
                 {
+                    if (!(a.dbg & 65536)) // experiment: weights only (their landing time alone)
+                    {
 #pragma unroll
                     for (int i = 0; i < kPatchIters - 1; i++)
                         if (nt_loads)
@@ -699,6 +721,8 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                         else
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
                                                              (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
+                    }
+                    if (!(a.dbg & 131072)) // experiment: patches only
 #pragma unroll
                     for (int i = 0; i < WPASS; i++)
                         if (i * 256 + lw * 64 < WITEMS)
@@ -746,6 +770,8 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
     if (tid < 16) reinterpret_cast<int*>(smem + 2 * STAGE + 256)[tid] = 0; // epilogue hand-shake flags (NT = 2)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the ds_write has landed before this wave's first barrier
 
+    // identity tap (see below): the first residual of an EPI-2 conv is this conv's own input planes 0,1
+    const bool idt = (EPI == 2 && NT == 2 && a.res1_in_acc && !(a.dbg & 64));
     int r = 0, ck = 0;
     WorkItem it = a.items[first];
     WorkItem nxt = a.items[first + (nmine > 1 ? nj : 0)];
@@ -816,6 +842,27 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
             __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
+        // Identity tap: out = s1*(conv + b) + x with x = input planes 0,1 of this very conv (RDB conv5, fp16 trunk).  While
+        // plane ntw (= this wave's 32 output channels) is in LDS the residual is added on the matrix pipe as one more
+        // "tap": A = (1/s1) * I (exact in fp16 for s1 = 0.2), B = the centre-tap pixel fragments -> acc += 5*x, exactly,
+        // so the epilogue has no residual to fetch (its global loads sat, un-hidden, in front of every row's stores).
+        if (idt && ck == ntw)
+        {
+            half8 idf[2], xc[2][4];
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++)
+            {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) idf[cb][jj] = (cb * 16 + hi * 8 + jj == l32) ? (_Float16)a.res1_coef : (_Float16)0.f;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+                    xc[cb][rr] = *reinterpret_cast<const half8*>(buf + ((xcol[1] ^ (cb << 5)) + (rr + 1) * (kPatchW * 64)));
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[cb], xc[cb][rr], acc[rr], 0, 0, 0);
+        }
         }
         if (++ck == nplanes)
         {
@@ -848,13 +895,15 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 else if (EPI == 3) {}
                 else if ((EPI == 1 || EPI == 2) && !(a.dbg & 64))
                 { // coalesced stores through a private LDS row of the patch that was just consumed
-                    volatile int* flags = reinterpret_cast<volatile int*>(smem + 2 * STAGE + 256);
-                    volatile int* mine = flags + wave;
-                    volatile int* partner = (NT == 2) ? flags + (wave ^ 4) : nullptr;
+                    char* flags = smem + 2 * STAGE + 256;
+                    char* mine = flags + wave * 4;
+                    char* partner = (NT == 2) ? flags + (wave ^ 4) * 4 : nullptr;
+                    char* pb = const_cast<char*>(buf);
+                    unsigned long long* ets = (tracing && s < 512) ? a.trace + 1024 + 8 * s : nullptr;
                     if (it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W)
-                        conv_epilogue_lds_row<(EPI == 2 ? 2 : 1), false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf), mine, partner, r + 1);
+                        conv_epilogue_lds_row<(EPI == 2 ? 2 : 1), false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, pb, mine, partner, r + 1, idt, ets);
                     else
-                        conv_epilogue_lds_row<(EPI == 2 ? 2 : 1), true>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, const_cast<char*>(buf), mine, partner, r + 1);
+                        conv_epilogue_lds_row<(EPI == 2 ? 2 : 1), true>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, lane, pb, mine, partner, r + 1, idt, ets);
                 }
                 else if (it.y0 + kBlkH <= it.H && it.x0 + kBlkW <= it.W)
                     conv_epilogue_t<EPI, false>(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
@@ -1001,6 +1050,9 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
             if (lw < 3) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
         };
+        // Two input chunks (the 64->32 convs): chunk ck always lands in weight buffer ck, so after the first block the two
+        // images ARE the conv's whole weight set -- keep them, and stream patches only (-31 % LDS-DMA bytes per stage).
+        const bool w_resident = (nplanes == 2) && !(a.dbg & 32768);
         issue_w(0, 0);
         int t = 0, slot3 = 0, wck = 1 % nplanes; // wck = chunk of the next weight image to issue, W(t-1) at loop index t
         for (int r = 0; r < nmine; r++)
@@ -1024,7 +1076,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
                 if (t >= 2)
                 {
                     wait_newest_patch_only_then_barrier(); // B_{t-2}
-                    issue_w(wck, (t - 1) & 1);             // W(t-1)
+                    if (!(w_resident && t >= 3)) issue_w(wck, (t - 1) & 1); // W(t-1)
                     wck = (wck + 1 == nplanes) ? 0 : wck + 1;
                 }
                 char* buf = smem + slot3 * kPatchLds + lw * 1024;
@@ -1050,7 +1102,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
         if (S >= 2)
         {
             wait_newest_patch_only_then_barrier(); // B_{S-2}
-            issue_w(wck, (S - 1) & 1);             // W(S-1)
+            if (!(w_resident && S >= 3)) issue_w(wck, (S - 1) & 1); // W(S-1)
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // B_{S-1}
         return;
@@ -1101,10 +1153,6 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
     // is folded to maxnum, which canonicalises the MFMA result first (one more v_max per value)
     float pinf = __builtin_inff();
     asm volatile("" : "+s"(pinf));
-#ifdef RSR_EXP_VALU
-    float exp_d[4] = {1.f, 2.f, 3.f, 4.f};
-    asm volatile("" : "+v"(exp_d[0]), "+v"(exp_d[1]), "+v"(exp_d[2]), "+v"(exp_d[3]));
-#endif
     half8 zfrag;
     {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -1332,53 +1380,10 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
                 RSR_LOAD_STEP(X0, W0, 4)
                 RSR_MFMA_STEP(X1, W1)
                 RSR_LOAD_STEP(X1, W1, 5)
-#ifdef RSR_EXP_PLAIN_ROWMAJOR // experiment: cost of six back-to-back dependent MFMAs
-                RSR_MAIN_SCHED()
-                __builtin_amdgcn_sched_barrier(0);
-                RSR_MFMA_ROW(0)
-                RSR_MFMA_ROW(1)
-                RSR_MFMA_ROW(2)
-                RSR_MFMA_ROW(3)
-#else
                 RSR_MFMA_STEP(X0, W0)
                 RSR_MFMA_STEP(X1, W1)
-#ifdef RSR_EXP_VALU // experiment: RSR_EXP_VALU independent VALU instructions per MFMA in the plain stage -- do they co-issue?
-#pragma unroll
-                for (int k = 0; k < 72 * RSR_EXP_VALU / 4; k++)
-                {
-                    exp_d[0] = __builtin_amdgcn_fmed3f(exp_d[0], slope, pinf);
-                    exp_d[1] = __builtin_amdgcn_fmed3f(exp_d[1], slope, pinf);
-                    exp_d[2] = __builtin_amdgcn_fmed3f(exp_d[2], slope, pinf);
-                    exp_d[3] = __builtin_amdgcn_fmed3f(exp_d[3], slope, pinf);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
-#pragma unroll
-                for (int tt = 0; tt < 4; tt++)
-                {
-#pragma unroll
-                    for (int g = 0; g < 3; g++)
-                    {
-#pragma unroll
-                        for (int m = 0; m < 4; m++)
-                        {
-                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, RSR_EXP_VALU, 0);
-                        }
-                        if (g < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        else __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 24; m++)
-                {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, RSR_EXP_VALU, 0);
-                }
-#else
                 RSR_MAIN_SCHED()
                 __builtin_amdgcn_sched_group_barrier(0x8, 24, 0);
-#endif
-#endif
             }
         }
         if (++ck == nplanes)
@@ -1409,9 +1414,6 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
             if (r < nmine) it = items[r];
         }
     }
-#ifdef RSR_EXP_VALU
-    if (exp_d[0] + exp_d[1] + exp_d[2] + exp_d[3] == 12345.678f) a.trace[0] = 1;
-#endif
 #undef RSR_LOAD_STEP
 #undef RSR_MFMA_STEP
 #undef RSR_MFMA_ROW

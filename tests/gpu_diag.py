@@ -228,6 +228,8 @@ def sec_trace():
     sr.tilesize = 200
     img = synth.make_image(3, 1920, 1080)
     sr.process(img)
+    if os.environ.get("RSR_TRACE_DBG"):
+        sr.set_option("dbg", int(os.environ["RSR_TRACE_DBG"]))
     for ci, name in [(1, "64->32"), (4, "160->32"), (5, "192->64")]:
         sr.set_option("trace_conv", ci)
         sr.process(img)
@@ -244,6 +246,14 @@ def sec_trace():
         print("    busy (release->next arrival): plain stages mean %.0f p50 %.0f | stages with epilogue mean %.0f p50 %.0f" % (
             busy[~last].mean(), np.median(busy[~last]), busy[last].mean(), np.median(busy[last])))
         print("    first 12 (wait,busy):", [(int(w), int(b)) for w, b in zip(wait[:12], busy[:12])])
+        if os.environ.get("RSR_OVLTRACE") and ci == 5:
+            full = sr.get_trace(8192).astype(np.int64)
+            ws = full[1024:1024 + 8 * n].reshape(n, 8)[:, :6]
+            rows = np.array([[ws[s_, 0] - release[s_]] + [ws[s_, k + 1] - ws[s_, k] for k in range(5)] +
+                             [(arrive[s_ + 1] - ws[s_, 5]) if s_ + 1 < n else 0] for s_ in range(n) if ws[s_, 0] > 0])
+            print("    NT=2 epilogue, ticks (median over %d): stage-MFMA %d | handshake %d | row0 %d | row1 %d | row2 %d | row3 %d | to-barrier %d" % (
+                (len(rows),) + tuple(int(np.median(rows[:, k])) for k in range(7))))
+            print("      p90:", [int(np.quantile(rows[:, k], 0.9)) for k in range(7)])
         if os.environ.get("RSR_OVLTRACE") and ci != 5:
             full = sr.get_trace(8192).astype(np.int64)
             ws = full[1024:1024 + 8 * n].reshape(n, 8)[:, :6]

@@ -151,7 +151,8 @@ int rsr_get_profile(rsr_ctx* ctx, rsr_profile* out, int reset);
 int rsr_get_conv_times(rsr_ctx* ctx, double* ms, int n, int reset);
 
 /* Profiling aid: after rsr_set_option("trace_conv", i) the launch of convolution i records, for workgroup 0 /
- * MFMA wave 0, the s_memtime stamps (arrival at, release from) every stage barrier; n <= 1024 values. */
+ * MFMA wave 0, the s_memtime stamps (arrival at, release from) every stage barrier in out[0..1023]; builds with
+ * -DRSR_EXP_OVLTRACE add per-stage epilogue stamps at out[1024 + 8*stage ..]; n <= 8192 values. */
 int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
 
 /* Engine knobs (optional).  key/value:
@@ -159,9 +160,18 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "trunk_fp32"        0 [default]: every feature tensor incl. the residual trunk is stored as fp16, like the
  *                       reference's Vulkan path (use_fp16_storage, realsr.cpp:45); 1: the trunk additionally lives
  *                       in fp32 (halves the pre-quantise error, costs ~15 % throughput)
- *   "kernel"            2 [default]: conv3x3_pipe (persistent, wave-specialised), 1: conv3x3_mfma
+ *   "kernel"            3 [default]: conv3x3_ring for the 32-output-channel convs (3-deep LDS-DMA patch ring, epilogue
+ *                       folded into the last stage) + conv3x3_pipe for the 64-output-channel ones; 2: conv3x3_pipe
+ *                       (persistent, wave-specialised, double-buffered) for everything; 1: conv3x3_mfma (first version)
  *   "use_dma"           kernel 1 only: LDS-DMA (1) or register staging (0)
- *   "num_cu", "dbg"     profiling aids (persistent grid size, ablation bits of ConvArgs::dbg) */
+ *   "num_cu"            persistent grid size (profiling aid)
+ *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace), -1 off
+ *   "stagger","ring_nt2" experiment switches (workgroup de-phasing; try the ring kernel for 64-cout convs: does not fit)
+ *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
+ *                         1 skip LDS-DMA, 2 skip MFMAs, 4 skip epilogue stores, 16 generic epilogue everywhere,
+ *                         32 no outbox, 64 direct epilogues (no LDS transpose, no in-stage epilogue, no identity tap),
+ *                         256 non-temporal epilogue stores, 512 non-temporal patch loads, 4096 no identity tap,
+ *                         32768 stream weights even when resident, 65536 / 131072 weights-only / patches-only DMA */
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
 
 const char* rsr_last_error(const rsr_ctx* ctx); /* ctx may be NULL: last global (create/pack) error */

@@ -204,6 +204,10 @@ int Engine::build_plan(int w, int h, int c)
             mtw = std::max(mtw, t.tw);
             mth = std::max(mth, t.th);
         }
+    // The kernels address a plane through 32-bit byte offsets (raw buffer resources, out-of-range sentinel 2^31): the
+    // largest plane is the 4x level, 16 * cap pixels * 64 B.  Tiles beyond that (~1,400 px) must be split by the caller.
+    if (cap * 16 * 64 >= (1ll << 31))
+        return fail(RSR_E_ARG, "tilesize too large: a padded tile may have at most 2,097,151 pixels (e.g. -t 1400)");
     const int per = tta ? 8 : 1;
     const long long per_slot = cap * kBytesPerPx;
     long long budget_slots = (max_workspace_mb * 1024 * 1024) / std::max<long long>(per_slot, 1);

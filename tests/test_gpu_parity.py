@@ -143,6 +143,41 @@ def test_network_tile_prequantise_error(sr, oracle_net, trunk_fp32):
     assert np.abs(q(got) - q(ref)).max() <= 1
 
 
+@pytest.mark.parametrize("w,h", [(28, 24), (64, 32), (45, 50)])
+def test_kernel_paths_agree(sr, w, h):
+    """The fast paths are restatements of the generic epilogue: in-stage epilogue of the ring kernel, LDS-row epilogue of
+    the 64-channel kernel, conv5's residual as an identity tap (ConvArgs::dbg switches them off).  Same arithmetic up to
+    one fp16 rounding of 0.2*x5 -> every variant stays within 2e-3 of the generic path and +-1 after quantisation."""
+    img = synth.make_image(17, w, h)
+    x = (img.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)).astype(np.float16)
+    q = lambda v: np.clip(np.floor(v * 255.0 + 0.5), 0, 255)
+    try:
+        sr.set_option("dbg", 16)  # generic epilogue everywhere
+        ref = sr.net_forward(x).astype(np.float32)
+        for kernel, dbg in [(3, 0), (3, 4096), (3, 64), (2, 0), (1, 0)]:
+            sr.set_option("kernel", kernel)
+            sr.set_option("dbg", dbg)
+            got = sr.net_forward(x).astype(np.float32)
+            assert np.isfinite(got).all(), (kernel, dbg)
+            d = np.abs(got - ref)
+            assert d.max() <= 2e-3, (kernel, dbg, d.max())
+            assert np.abs(q(got) - q(ref)).max() <= 1
+    finally:
+        sr.set_option("kernel", 3)
+        sr.set_option("dbg", 0)
+
+
+def test_oversized_tile_is_refused(sr):
+    """32-bit plane offsets: a padded tile above 2^21 pixels is an argument error, not a wrong image."""
+    sr.tilesize = 2000
+    try:
+        with pytest.raises(R.RealSRError) as e:
+            sr.process(np.zeros((1500, 1500, 3), np.uint8))
+        assert e.value.code == R.RSR_E_ARG
+    finally:
+        sr.tilesize = 200
+
+
 # ---- end to end through rsr_process ---------------------------------------------------------------------
 E2E = [(50, 43, 3, 32, False), (70, 20, 3, 64, False), (24, 20, 3, 200, False), (5, 3, 3, 32, False),
        (33, 64, 3, 32, False), (37, 20, 4, 32, False), (40, 33, 3, 32, True), (21, 38, 4, 16, True)]

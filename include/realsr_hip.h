@@ -170,8 +170,7 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
  *                         1 skip LDS-DMA, 2 skip MFMAs, 4 skip epilogue stores, 16 generic epilogue everywhere,
  *                         32 no outbox, 64 direct epilogues (no LDS transpose, no in-stage epilogue, no identity tap),
- *                         256 non-temporal epilogue stores, 512 non-temporal patch loads, 4096 no identity tap,
- *                         32768 stream weights even when resident, 65536 / 131072 weights-only / patches-only DMA */
+ *                         4096 no identity tap, 32768 stream weights even when resident */
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
 
 const char* rsr_last_error(const rsr_ctx* ctx); /* ctx may be NULL: last global (create/pack) error */

@@ -235,11 +235,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
             const int y = y0 + wrow * 4 + half * 2 + rl, x = x0 + col;
             if (!CHECK || (y < H && x < W))
             {
-                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                u32x4* dstp = reinterpret_cast<u32x4*>(op + ((long long)y * W + x) * 64 + rpiece * 16);
-                const u32x4 vv = {v.x, v.y, v.z, v.w};
-                if (a.dbg & 256) __builtin_nontemporal_store(vv, dstp); // experiment: streaming stores
-                else *dstp = vv;
+                *reinterpret_cast<uint4*>(op + ((long long)y * W + x) * 64 + rpiece * 16) = v;
             }
         }
     }
@@ -361,9 +357,7 @@ __device__ __forceinline__ void conv_epilogue_lds_row(const ConvArgs& a, f32x16 
             const int y = y0 + wrow * 4 + rr, x = x0 + col;
             if (!CHECK || (y < H && x < W))
             {
-                half8* dstp = reinterpret_cast<half8*>(op + ((long long)y * W + x) * 64 + rpiece * 16);
-                if (a.dbg & 256) __builtin_nontemporal_store(t, dstp);
-                else *dstp = t;
+                *reinterpret_cast<half8*>(op + ((long long)y * W + x) * 64 + rpiece * 16) = t;
             }
         }
         RSR_ETS(2 + rr)
@@ -645,7 +639,6 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
     {
         // ================= loader waves =================
         const int lw = wave - NCW, ltid = lw * 64 + lane;
-        const bool nt_loads = a.dbg & 512; // experiment: non-temporal policy on the activation stream
                 const char* wbase = static_cast<const char*>(a.wpk);
         int t = 0;
         WorkItem nxt = a.items[first];
@@ -704,25 +697,15 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 const char* wsrc = wbase + (long long)ck * (WROWS * 64) + (lw * 64 + lane) * 16;
                 if (!(a.dbg & 1))
                 {
-                    if (!(a.dbg & 65536)) // experiment: weights only (their landing time alone)
                     {
 #pragma unroll
                     for (int i = 0; i < kPatchIters - 1; i++)
-                        if (nt_loads)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
-                                                             (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 2);
-                        else
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
                                                              (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
                     if (lw < 3) // the patch region is 39 one-KiB pieces: the last pass has only three
-                        if (nt_loads)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
-                                                             (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 2);
-                        else
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
                                                              (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
                     }
-                    if (!(a.dbg & 131072)) // experiment: patches only
 #pragma unroll
                     for (int i = 0; i < WPASS; i++)
                         if (i * 256 + lw * 64 < WITEMS)
@@ -1034,9 +1017,9 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
         // so before barrier B_s the newest NP instructions are exactly P(s+1) and "s_waitcnt vmcnt(NP)" means
         // "P(s), W(s) and everything older have landed" (vector loads retire in order).
         const int lw = wave - NCW, ltid = lw * 64 + lane;
-        const bool nt_loads = a.dbg & 512; // experiment: non-temporal policy on the activation stream
         const char* wbase = static_cast<const char*>(a.wpk) + (lw * 64 + lane) * 16;
         auto issue_w = [&](int wck, int wsel) {
+            if (a.dbg & 1) return; // ablation: no LDS-DMA
             const char* wsrc = wbase + (long long)wck * WBYTES;
             char* wb = smem + WOFF + wsel * WBYTES + lw * 1024;
 #pragma unroll
@@ -1082,21 +1065,14 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
                 char* buf = smem + slot3 * kPatchLds + lw * 1024;
                 slot3 = slot3 == kRingDepth - 1 ? 0 : slot3 + 1;
                 const char* gbase = ((ck < a.n0) ? plane_ptr(a.src0, it.slot, ck) : plane_ptr(a.src1, it.slot, ck - a.n0)) - kGuard;
+                if (a.dbg & 1) continue; // ablation: no LDS-DMA
 #pragma unroll
                 for (int i = 0; i < kPatchIters - 1; i++)
-                    if (nt_loads)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
-                                                         (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 2);
-                    else
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
-                                                         (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[i]),
+                                                     (__attribute__((address_space(3))) void*)(buf + i * 4096), 16, 0, 0);
                 if (lw < 3)
-                    if (nt_loads)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
-                                                         (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 2);
-                    else
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
-                                                         (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + srcoff[kPatchIters - 1]),
+                                                     (__attribute__((address_space(3))) void*)(buf + (kPatchIters - 1) * 4096), 16, 0, 0);
             }
         }
         if (S >= 2)

@@ -166,6 +166,8 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "use_dma"           kernel 1 only: LDS-DMA (1) or register staging (0)
  *   "num_cu"            persistent grid size (profiling aid)
  *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace), -1 off
+ *   "alternate_order"   1 [default]: every second conv walks its work items backwards (starts on the tiles the previous conv
+ *                       touched last -> Infinity Cache hits); 0: always forwards
  *   "stagger","ring_nt2" experiment switches (workgroup de-phasing; try the ring kernel for 64-cout convs: does not fit)
  *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
  *                         1 skip LDS-DMA, 2 skip MFMAs, 4 skip epilogue stores, 16 generic epilogue everywhere,

@@ -340,6 +340,8 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
                 return ctx->e.fail(RSR_E_DEVICE, "trace buffer clear");
         }
     }
+    else if (k == "alternate_order")
+        ctx->e.alternate_order = value != 0;
     else if (k == "stagger")
         ctx->e.stagger_unit = int(value);
     else if (k == "dbg")

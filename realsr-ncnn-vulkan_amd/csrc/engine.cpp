@@ -159,7 +159,7 @@ static size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
 static size_t batch_table_bytes(const Plan::Batch& b)
 {
     size_t n = al256(b.tiles.size() * sizeof(BaseTile)) + al256(b.dims.size() * sizeof(TileDim));
-    for (int l = 0; l < 3; l++) n += al256(b.items[l].size() * sizeof(WorkItem));
+    for (int l = 0; l < 3; l++) n += 2 * al256(b.items[l].size() * sizeof(WorkItem));
     return n;
 }
 
@@ -253,7 +253,11 @@ int Engine::build_plan(int w, int h, int c)
         b.d_tiles = static_cast<BaseTile*>(put(b.tiles.data(), b.tiles.size() * sizeof(BaseTile)));
         b.d_dims = static_cast<TileDim*>(put(b.dims.data(), b.dims.size() * sizeof(TileDim)));
         for (int l = 0; l < 3; l++)
+        {
             b.d_items[l] = static_cast<WorkItem*>(put(b.items[l].data(), b.items[l].size() * sizeof(WorkItem)));
+            std::vector<WorkItem> rev(b.items[l].rbegin(), b.items[l].rend());
+            b.d_items_rev[l] = static_cast<WorkItem*>(put(rev.data(), rev.size() * sizeof(WorkItem)));
+        }
     }
     HIP_TRY(hipGetLastError());
     return RSR_OK;
@@ -391,7 +395,10 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         a.lrelu = (c.act == 2);
         a.lvl_in = lvl_in;
         a.lvl_out = lvl_out;
-        a.items = b.d_items[lvl_out];
+        // Boustrophedon: every second conv walks the blocks backwards, so it starts on the tiles the previous conv
+        // produced (and read) last -- those are still in the 256 MB Infinity Cache; walking forwards again would start
+        // on the least recently used data.
+        a.items = (alternate_order && (ci & 1)) ? b.d_items_rev[lvl_out] : b.d_items[lvl_out];
         a.nitems = int(b.items[lvl_out].size());
         a.dims = b.d_dims;
         a.zeros = zeros.p;

@@ -40,6 +40,7 @@ struct Plan
         BaseTile* d_tiles = nullptr;
         TileDim* d_dims = nullptr;
         WorkItem* d_items[3] = {nullptr, nullptr, nullptr};
+        WorkItem* d_items_rev[3] = {nullptr, nullptr, nullptr}; // the same blocks in reverse order (see run_network)
     };
     std::vector<Batch> batches;
     int slots_per_batch = 0;
@@ -59,6 +60,7 @@ struct Engine
     bool ring_nt2 = false; // use conv3x3_ring also for 64-output-channel convs (slower there: 168-VGPR budget)
     int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
     int stagger_unit = 0; // s_sleep units (64 cycles) per (chunk + 2) of start delay between workgroup phases
+    bool alternate_order = true; // odd convs walk the work items backwards: they start on the data the previous conv touched last
     int trace_conv = -1; // conv index whose launch records s_memtime stamps into trace_buf (profiling only)
     DevBuf trace_buf;
     long long max_workspace_mb = 65536;

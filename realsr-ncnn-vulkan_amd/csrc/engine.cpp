@@ -398,7 +398,7 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         // Boustrophedon: every second conv walks the blocks backwards, so it starts on the tiles the previous conv
         // produced (and read) last -- those are still in the 256 MB Infinity Cache; walking forwards again would start
         // on the least recently used data.
-        a.items = (alternate_order && (ci & 1)) ? b.d_items_rev[lvl_out] : b.d_items[lvl_out];
+        a.items = (alternate_order && (ci & 1) && b.d_items_rev[lvl_out]) ? b.d_items_rev[lvl_out] : b.d_items[lvl_out];
         a.nitems = int(b.items[lvl_out].size());
         a.dims = b.d_dims;
         a.zeros = zeros.p;

@@ -72,11 +72,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Test hook for a 1-GPU box: RSR_BENCH_SAME_GPU=1 puts every rank on cuda:0 and RSR_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device), so the multi-rank control flow can be exercised without 2 GPUs.
+    if os.environ.get("RSR_BENCH_SAME_GPU") == "1":
+        local = 0
+    backend = os.environ.get("RSR_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -281,3 +281,23 @@ def test_full_hd_properties(sr, oracle_net):
     ref8 = np.clip((ref * 255.0 + 0.5).astype(np.int32), 0, 255).transpose(1, 2, 0)
     d = np.abs(a[1600:2400, 2400:3200].astype(int) - ref8)
     assert d.max() <= 1
+
+
+def test_baseline_config_c1_against_oracle(oracle_net):
+    """BASELINE config C1 at full size: 256x256 RGB, tile 128 (2x2 tiles of 148x148 padded), the JPEG-model weights
+    (seed 43).  The whole frame against the CPU restatement: +-1 uint8 everywhere."""
+    import tempfile
+    d = synth.make_model_dir(tempfile.mkdtemp(prefix="rsr_c1_"), "models-DF2K_JPEG", 43)
+    pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+    net = oracle.OracleNet(pp, bp)
+    img = synth.make_image(1235, 256, 256)
+    ref = net.process(img, 128)
+    s = R.RealSR(0)
+    s.load(pp, bp)
+    s.tilesize = 128
+    got = s.process(img)
+    s.close()
+    assert got.shape == ref.shape == (1024, 1024, 3)
+    dd = np.abs(got.astype(int) - ref.astype(int))
+    assert dd.max() <= 1
+    assert (dd > 0).mean() < 0.15

@@ -38,5 +38,5 @@ def run(nctx, num_cu, ws, frames=4):
     return same
 
 
-for cfg in [(1, 256, 65536), (2, 128, 65536), (2, 128, 6100), (2, 128, 3100), (2, 128, 1600), (2, 256, 3100), (3, 80, 3100), (4, 64, 1600)]:
+for cfg in [(1, 256, 65536), (1, 256, 6100), (2, 256, 65536), (2, 256, 9400), (2, 256, 6100), (2, 256, 4000), (2, 256, 3100), (2, 256, 2200), (3, 256, 3100), (3, 256, 2200)]:
     print("  identical outputs:", run(*cfg))

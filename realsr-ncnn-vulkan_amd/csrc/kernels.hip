@@ -1409,15 +1409,31 @@ static bool launch_conv_ring_t(const ConvArgs& a, int ncu, hipStream_t st)
     const int per = (a.nitems + 7) / 8;
     if (per * 8 < grid) grid = per * 8;
     const int nj = grid / 8, nmine_max = (per + nj - 1) / nj;
-    const size_t lds = size_t(kRingDepth) * kPatchLds + 2 * size_t(9 * NT * 32 * 64) + 256 + size_t(nmine_max) * sizeof(WorkItem);
-    if (lds > 160 * 1024) return false; // does not fit (64 output channels, or a very long descriptor list): use conv3x3_pipe
+    const size_t fixed = size_t(kRingDepth) * kPatchLds + 2 * size_t(9 * NT * 32 * 64) + 256;
+    if (fixed + sizeof(WorkItem) > 160 * 1024) return false; // 64 output channels: two weight images do not fit, use conv3x3_pipe
     static bool attr_set = false;
     if (!attr_set)
     {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring<NT, UPS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_ring<NT, UPS, EPI>), dim3(grid), dim3((4 * NT + 4) * 64), lds, st, a);
+    // The workgroup keeps its work-item descriptors in LDS; a list that does not fit (the 4x level has 16x the blocks) is
+    // walked in several launches -- they read the same finished input and write disjoint blocks, stream order suffices.
+    const int cap_items = int((160 * 1024 - fixed) / sizeof(WorkItem));
+    const int nsub = (nmine_max + cap_items - 1) / cap_items;
+    const int chunk = (a.nitems + nsub - 1) / nsub;
+    for (int off = 0; off < a.nitems; off += chunk)
+    {
+        ConvArgs s = a;
+        s.items = a.items + off;
+        s.nitems = a.nitems - off < chunk ? a.nitems - off : chunk;
+        int g = ncu & ~7;
+        const int p = (s.nitems + 7) / 8;
+        if (p * 8 < g) g = p * 8;
+        const int njs = g / 8, nm = (p + njs - 1) / njs;
+        const size_t lds = fixed + size_t(nm) * sizeof(WorkItem);
+        hipLaunchKernelGGL((conv3x3_ring<NT, UPS, EPI>), dim3(g), dim3((4 * NT + 4) * 64), lds, st, s);
+    }
     return true;
 }
 

@@ -188,8 +188,8 @@ def main():
                 "frac": round(ach / PEAK_F16_TFLOPS, 4),
                 # HBM bytes per launch of this kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
                 # command (profiles/r01_pmc_traffic.txt; FETCH_SIZE doubled per the gfx950 correction of
-                # MI355X_MICROARCH.md): 580.6 MB read + 163.0 MB written.  Algorithmic: (3.5 + 1) planes x 162.8 MB.
-                "traffic": 743.6e6,
+                # MI355X_MICROARCH.md): 585.3 MB read + 162.9 MB written.  Algorithmic: (3.5 + 1) planes x 162.8 MB.
+                "traffic": 748.2e6,
                 "traffic_unit": "B/launch (PMC, separate passes; algorithmic 732.7e6)",
                 "kernel": "rsr::conv3x3_ring<1,false,1> (276 of the 351 convs: cin 64..160 -> 32, LeakyReLU, fp16 planes)",
                 "launches": ring_launches,

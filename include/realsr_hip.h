@@ -13,7 +13,11 @@
  *   - images are HWC uint8, tightly packed, c in {3,4}, RGB(A) order (main.cpp:275-276); the output is
  *     caller-allocated (w*scale) x (h*scale) x c.  The engine never retains either pointer.
  *   - one context per GPU (main.cpp:778-791); rsr_process* are thread-safe on a shared context
- *     (the reference calls process() concurrently from jobs_proc threads, main.cpp:811-828).
+ *     (the reference calls process() concurrently from jobs_proc threads, main.cpp:811-828): every
+ *     call owns private device image buffers, pinned staging and a copy stream ("lane", up to
+ *     max_lanes in flight, further callers wait); the network kernels of all calls are queued on one
+ *     compute stream, so upload(k+1) | kernels(k) | download(k-1) overlap.
+ *   - rsr_last_error() reports the CALLING THREAD's most recent failure.
  *   - there is NO CPU fallback: gpuid must name a HIP device; the reference's "-g -1" CPU path
  *     (RealSR::process_cpu) lives only in oracle/ as the parity checker.
  */
@@ -72,6 +76,17 @@ int rsr_process(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* o
  * given: the caller synchronises. */
 int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void* d_out, void* stream);
 
+/* Pinned host memory for images.  rsr_process copies pinned buffers (these, hipHostMalloc'd or hipHostRegister'ed
+ * memory) to / from the GPU directly; pageable memory goes through the call's pinned staging (the download in chunks,
+ * the CPU copy of one chunk under the PCIe transfer of the next).  The reference gets the same from ncnn's Vulkan
+ * staging allocator (realsr.cpp:161-167, 208-220). */
+void* rsr_host_alloc(size_t bytes);
+void rsr_host_free(void* p);
+
+/* The reference prints one line per tile to stderr (realsr.cpp:481).  Here all tiles of a batch run together: `cb` is
+ * called (from the calling thread, kernels enqueued but not necessarily finished) after each tile batch. */
+int rsr_set_progress_callback(rsr_ctx* ctx, void (*cb)(int tiles_done, int tiles_total, void* user), void* user);
+
 /* ---- weights as one relocatable blob (multi-GPU load path) -------------------------------- */
 /* The reference re-reads x4.bin once per GPU (main.cpp:784-786).  Here rank 0 parses and packs once,
  * the blob travels by a single RCCL broadcast over xGMI (done by the caller, e.g.
@@ -80,6 +95,9 @@ int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void
 /* Host-only: parse + validate + pack into `dst` (capacity `cap` bytes).  *need receives the blob
  * size; call with dst=NULL to query.  No GPU required. */
 int rsr_model_pack(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need);
+/* with_w32 = 0 leaves out the weight images of the round-1 kernels ("kernel" 1-3): 33.5 MB instead of 67 MB -- the blob
+ * the multi-GPU broadcast carries.  rsr_model_pack = with_w32 1. */
+int rsr_model_pack_ex(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need, int with_w32);
 
 /* Load a blob produced by rsr_model_pack.  `blob` may be a host pointer (is_device=0) or a device
  * pointer on this context's GPU (is_device=1). */
@@ -157,22 +175,27 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
 
 /* Engine knobs (optional).  key/value:
  *   "max_workspace_mb"  tile-batch memory budget (default 65536)
+ *   "kernel"            4 [default]: conv3x3_flow -- 16-channel planes, 16-channel half-stage LDS ring, fragments reloaded
+ *                       in place across stage and block boundaries, mid-stream barrier, deferred epilogue (conv_flow.hip);
+ *                       3: conv3x3_ring (32-output-channel convs) + conv3x3_pipe (64), 2: conv3x3_pipe for everything,
+ *                       1: conv3x3_mfma -- the round-1 kernels on 32-channel planes, kept as second implementations
  *   "trunk_fp32"        0 [default]: every feature tensor incl. the residual trunk is stored as fp16, like the
  *                       reference's Vulkan path (use_fp16_storage, realsr.cpp:45); 1: the trunk additionally lives
- *                       in fp32 (halves the pre-quantise error, costs ~15 % throughput)
- *   "kernel"            3 [default]: conv3x3_ring for the 32-output-channel convs (3-deep LDS-DMA patch ring, epilogue
- *                       folded into the last stage) + conv3x3_pipe for the 64-output-channel ones; 2: conv3x3_pipe
- *                       (persistent, wave-specialised, double-buffered) for everything; 1: conv3x3_mfma (first version)
+ *                       in fp32 (halves the pre-quantise error; served by the kernel-3 path, ~-25 % throughput)
+ *   "flow_flags"        kernel 4: bit 0 = 64-output-channel convs with 4 MFMA waves x 64 channels instead of 8 x 32,
+ *                       bit 1 = no deferred epilogue for the 32-output-channel convs
  *   "use_dma"           kernel 1 only: LDS-DMA (1) or register staging (0)
+ *   "max_lanes"         rsr_process calls in flight per context (default 4); "chunk_mb": download chunk for pageable
+ *                       destinations (default 16)
  *   "num_cu"            persistent grid size (profiling aid)
- *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace), -1 off
+ *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; kernels 2/3, or a
+ *                       -DRSR_FLOW_TRACE build of kernel 4), -1 off
  *   "alternate_order"   1 [default]: every second conv walks its work items backwards (starts on the tiles the previous conv
  *                       touched last -> Infinity Cache hits); 0: always forwards
- *   "stagger","ring_nt2" experiment switches (workgroup de-phasing; try the ring kernel for 64-cout convs: does not fit)
  *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
- *                         1 skip LDS-DMA, 2 skip MFMAs, 4 skip epilogue stores, 16 generic epilogue everywhere,
- *                         32 no outbox, 64 direct epilogues (no LDS transpose, no in-stage epilogue, no identity tap),
- *                         4096 no identity tap, 32768 stream weights even when resident */
+ *                         1 skip LDS-DMA, 2 skip MFMAs (kernels 2/3), 4 skip epilogue stores, 16 generic epilogue everywhere
+ *                         (kernels 2/3), 64 direct epilogues (kernels 2/3), 4096 no identity tap, 32768 stream weights even
+ *                         when resident (kernel 3) */
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
 
 const char* rsr_last_error(const rsr_ctx* ctx); /* ctx may be NULL: last global (create/pack) error */

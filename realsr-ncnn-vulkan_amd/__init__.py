@@ -23,7 +23,8 @@ EXPORTS = [
     "rsr_create", "rsr_destroy", "rsr_load", "rsr_set_params", "rsr_process", "rsr_process_device",
     "rsr_model_pack", "rsr_load_packed", "rsr_model_info", "rsr_preproc", "rsr_preproc_tta", "rsr_postproc",
     "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times", "rsr_get_trace",
-    "rsr_set_option", "rsr_last_error", "rsr_version",
+    "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_model_pack_ex", "rsr_host_alloc", "rsr_host_free",
+    "rsr_set_progress_callback",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -81,6 +82,12 @@ def lib():
     L.rsr_process.argtypes = [vp, vp, ip, ip, ip, vp]
     L.rsr_process_device.argtypes = [vp, vp, ip, ip, ip, vp, vp]
     L.rsr_model_pack.argtypes = [cp, cp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rsr_model_pack_ex.argtypes = [cp, cp, vp, C.c_size_t, C.POINTER(C.c_size_t), ip]
+    L.rsr_host_alloc.argtypes = [C.c_size_t]
+    L.rsr_host_alloc.restype = vp
+    L.rsr_host_free.argtypes = [vp]
+    L.rsr_host_free.restype = None
+    L.rsr_set_progress_callback.argtypes = [vp, vp, vp]
     L.rsr_load_packed.argtypes = [vp, vp, C.c_size_t, ip]
     L.rsr_model_info.argtypes = [cp, cp, C.POINTER(ip), C.POINTER(ip), C.POINTER(C.c_longlong),
                                  C.POINTER(C.c_longlong), C.POINTER(ip)]
@@ -117,18 +124,43 @@ def model_info(param_path, bin_path):
     return dict(n_layers=nl.value, n_convs=nc.value, n_weights=nw.value, n_biases=nb.value, bin_encoding=enc.value)
 
 
-def model_pack(param_path, bin_path):
-    """Host-only: parse, validate and pack the model into one relocatable blob (np.uint8 array)."""
+def model_pack(param_path, bin_path, with_w32=True):
+    """Host-only: parse, validate and pack the model into one relocatable blob (np.uint8 array).
+    with_w32=False leaves out the weight images of the round-1 kernels (the broadcast blob)."""
     L = lib()
     need = C.c_size_t()
-    rc = L.rsr_model_pack(str(param_path).encode(), str(bin_path).encode(), None, 0, need)
+    rc = L.rsr_model_pack_ex(str(param_path).encode(), str(bin_path).encode(), None, 0, need, int(with_w32))
     if rc != 0:
         raise RealSRError(rc, L.rsr_last_error(None).decode())
     buf = np.zeros(need.value, dtype=np.uint8)
-    rc = L.rsr_model_pack(str(param_path).encode(), str(bin_path).encode(), _p(buf), buf.size, need)
+    rc = L.rsr_model_pack_ex(str(param_path).encode(), str(bin_path).encode(), _p(buf), buf.size, need, int(with_w32))
     if rc != 0:
         raise RealSRError(rc, L.rsr_last_error(None).decode())
     return buf
+
+
+class PinnedArray:
+    """A numpy uint8 view of rsr_host_alloc'ed (pinned) memory; free() or let it go out of scope."""
+
+    def __init__(self, shape):
+        self._L = lib()
+        n = int(np.prod(shape))
+        self._p = self._L.rsr_host_alloc(n)
+        if not self._p:
+            raise MemoryError("rsr_host_alloc(%d)" % n)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * n).from_address(self._p)).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            self._L.rsr_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class RealSR:
@@ -181,11 +213,15 @@ class RealSR:
     def set_option(self, key, value):
         self._ck(self._L.rsr_set_option(self._h, key.encode(), int(value)))
 
-    def process(self, img):
-        img = np.ascontiguousarray(img, dtype=np.uint8)
+    def process(self, img, out=None, push_params=True):
+        """out: optional preallocated (4h, 4w, c) uint8 array (e.g. PinnedArray(...).array)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8) if not (isinstance(img, np.ndarray) and img.flags.c_contiguous and img.dtype == np.uint8) else img
         h, w, c = img.shape
-        self._push_params()
-        out = np.empty((h * self.scale, w * self.scale, c), dtype=np.uint8)
+        if push_params:
+            self._push_params()
+        if out is None:
+            out = np.empty((h * self.scale, w * self.scale, c), dtype=np.uint8)
+        assert out.shape == (h * self.scale, w * self.scale, c) and out.dtype == np.uint8 and out.flags.c_contiguous
         self._ck(self._L.rsr_process(self._h, _p(img), w, h, c, _p(out)))
         return out
 

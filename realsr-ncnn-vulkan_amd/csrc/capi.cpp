@@ -13,7 +13,9 @@ struct rsr_ctx
     Engine e;
 };
 
-static thread_local std::string g_err;
+// Errors raised before a context exists (rsr_create, rsr_model_pack) and errors of a context share one per-thread
+// message: rsr_last_error() always reports the calling thread's most recent failure.
+#define g_err_set(msg) ((void)Engine::fail(0, (msg)))
 
 #define CK(expr)                                                          \
     do                                                                    \
@@ -29,29 +31,52 @@ static thread_local std::string g_err;
 #pragma GCC visibility push(default)
 extern "C" {
 
-const char* rsr_version(void) { return "realsr-hip 0.1 (gfx950)"; }
+const char* rsr_version(void) { return "realsr-hip 0.2 (gfx950)"; }
 
-const char* rsr_last_error(const rsr_ctx* ctx) { return ctx ? ctx->e.err.c_str() : g_err.c_str(); }
+// Pinned host memory: images allocated here are copied to / from the GPU without the staging copy (the reference's
+// Vulkan path gets the same effect from its staging allocator, realsr.cpp:161-167).
+void* rsr_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        Engine::fail(RSR_E_NOMEM, "hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void rsr_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+int rsr_set_progress_callback(rsr_ctx* ctx, void (*cb)(int done, int total, void* user), void* user)
+{
+    if (!ctx) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
+    ctx->e.progress = cb;
+    ctx->e.progress_user = user;
+    return RSR_OK;
+}
+
+const char* rsr_last_error(const rsr_ctx* ctx)
+{
+    (void)ctx;
+    return rsr::last_error();
+}
 
 int rsr_create(rsr_ctx** out, int gpuid, int tta_mode, int num_threads)
 {
     (void)num_threads;
-    if (!out)
-    {
-        g_err = "null out pointer";
-        return RSR_E_ARG;
-    }
+    if (!out) return Engine::fail(RSR_E_ARG, "null out pointer");
     *out = nullptr;
     rsr_ctx* c = new (std::nothrow) rsr_ctx;
-    if (!c)
-    {
-        g_err = "out of memory";
-        return RSR_E_NOMEM;
-    }
+    if (!c) return Engine::fail(RSR_E_NOMEM, "out of memory");
     const int rc = c->e.init(gpuid, tta_mode);
     if (rc != RSR_OK)
     {
-        g_err = c->e.err;
         delete c;
         return rc;
     }
@@ -64,6 +89,7 @@ void rsr_destroy(rsr_ctx* ctx) { delete ctx; }
 int rsr_load(rsr_ctx* ctx, const char* parampath, const char* modelpath)
 {
     if (!ctx) return RSR_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->e.mu);
     return ctx->e.load_files(parampath, modelpath);
 }
 
@@ -94,18 +120,21 @@ int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void
 
 int rsr_model_pack(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need)
 {
-    if (!parampath || !modelpath)
-    {
-        g_err = "null path";
-        return RSR_E_ARG;
-    }
+    return rsr_model_pack_ex(parampath, modelpath, dst, cap, need, 1);
+}
+
+int rsr_model_pack_ex(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need, int with_w32)
+{
+    if (!parampath || !modelpath) return Engine::fail(RSR_E_ARG, "null path");
     Model m;
-    int rc = load_model(parampath, modelpath, m, g_err);
-    if (rc != RSR_OK) return rc;
-    const size_t n = packed_size(m);
+    std::string err;
+    int rc = load_model(parampath, modelpath, m, err);
+    if (rc != RSR_OK) return Engine::fail(rc, err);
+    const size_t n = packed_size(m, with_w32 != 0);
     if (need) *need = n;
     if (!dst) return RSR_OK;
-    return pack_model(m, dst, cap, g_err);
+    rc = pack_model(m, dst, cap, err, with_w32 != 0);
+    return rc == RSR_OK ? RSR_OK : Engine::fail(rc, err);
 }
 
 int rsr_load_packed(rsr_ctx* ctx, const void* blob, size_t bytes, int is_device)
@@ -118,14 +147,11 @@ int rsr_load_packed(rsr_ctx* ctx, const void* blob, size_t bytes, int is_device)
 int rsr_model_info(const char* parampath, const char* modelpath, int* n_layers, int* n_convs, long long* n_weights,
                    long long* n_biases, int* bin_encoding)
 {
-    if (!parampath || !modelpath)
-    {
-        g_err = "null path";
-        return RSR_E_ARG;
-    }
+    if (!parampath || !modelpath) return Engine::fail(RSR_E_ARG, "null path");
     Model m;
-    const int rc = load_model(parampath, modelpath, m, g_err);
-    if (rc != RSR_OK) return rc;
+    std::string err;
+    const int rc = load_model(parampath, modelpath, m, err);
+    if (rc != RSR_OK) return Engine::fail(rc, err);
     if (n_layers) *n_layers = m.n_layers;
     if (n_convs) *n_convs = int(m.convs.size());
     if (n_weights) *n_weights = m.n_weights;
@@ -310,8 +336,7 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     if (k == "max_workspace_mb")
     {
         if (value < 1) return ctx->e.fail(RSR_E_ARG, "max_workspace_mb must be >= 1");
-        ctx->e.max_workspace_mb = value;
-        ctx->e.free_plan();
+        ctx->e.max_workspace_mb = value; // plans are keyed by the budget: the next call builds a new one
     }
     else if (k == "trunk_fp32")
         ctx->e.trunk_fp32 = value != 0;
@@ -319,11 +344,22 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         ctx->e.use_dma = value != 0;
     else if (k == "kernel")
     {
-        if (value < 1 || value > 3) return ctx->e.fail(RSR_E_ARG, "kernel must be 1, 2 or 3");
+        if (value < 1 || value > 4) return ctx->e.fail(RSR_E_ARG, "kernel must be 1, 2, 3 or 4");
         ctx->e.kernel_version = int(value);
     }
-    else if (k == "ring_nt2")
-        ctx->e.ring_nt2 = value != 0;
+    else if (k == "flow_flags")
+        ctx->e.flow_flags = int(value);
+    else if (k == "max_lanes")
+    {
+        if (value < 1 || value > 64) return ctx->e.fail(RSR_E_ARG, "max_lanes out of range");
+        std::lock_guard<std::mutex> ll(ctx->e.lane_mu);
+        ctx->e.max_lanes = int(value);
+    }
+    else if (k == "chunk_mb")
+    {
+        if (value < 1 || value > 4096) return ctx->e.fail(RSR_E_ARG, "chunk_mb out of range");
+        ctx->e.chunk_bytes = size_t(value) << 20;
+    }
     else if (k == "trace_conv")
     {
         ctx->e.trace_conv = int(value);
@@ -342,8 +378,6 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     }
     else if (k == "alternate_order")
         ctx->e.alternate_order = value != 0;
-    else if (k == "stagger")
-        ctx->e.stagger_unit = int(value);
     else if (k == "dbg")
         ctx->e.dbg = int(value);
     else if (k == "num_cu")

@@ -1,0 +1,886 @@
+// conv_flow.hip -- conv3x3_flow: the 3x3 convolutions of x4.param as MFMA implicit GEMM on 16-channel planes,
+// streamed through LDS in 16-channel HALF-STAGES (gfx950 / MI355X only).
+//
+// Why a second generation (round-1 kernels: conv3x3_ring / conv3x3_pipe in kernels.hip): s_memtime traces of those
+// showed the matrix pipe idle for (a) the fragment refill after every stage barrier, (b) LDS-DMA data that had not
+// landed (64-output-channel convs: one 77-KB stage of look-ahead < the ~6,000-cycle DMA latency under load) and
+// (c) the epilogue, which is bound by the ~7-14 B/clk/CU at which a CU can issue global stores and used the patch
+// slot as transpose scratch (so the slot could not be refilled meanwhile).  This kernel removes all three:
+//
+//   * K is walked in units of ONE 16-channel plane (a "half-stage": 36 MFMAs per 32 output channels).  A half-stage
+//     is a 20-KB patch + a 9-KB (x NT) weight image, so 6 (NT=1) / 4 (NT=2) patches and 3 weight images ride in a
+//     ring next to a dedicated transpose scratch: 5 / 3 half-stages of look-ahead instead of 2 / 1 stages.
+//   * activations live in HBM as 16-channel planes [H][W][16] fp16 (32 B per pixel), so every LDS-DMA piece and
+//     every epilogue store is 1 KiB of whole cache lines; one v_mfma_f32_32x32x16_f16 consumes exactly one plane.
+//   * the MFMA waves never drain: operand fragments are reloaded IN PLACE, one (dx) step ahead, across half-stage
+//     and block boundaries; the 12 (dy, row) cells of a step run in anti-diagonal order so that fragment X[j] is dead
+//     after diagonal j and its reload has >= 10 MFMA slots to land.  The single s_barrier per half-stage sits in the
+//     middle of the MFMA stream, after the wave's last LDS read of the half-stage ("early barrier": the slot is
+//     handed back to the loaders a third of a half-stage before its MFMAs finish).
+//   * epilogue: bias enters as the C operand of the block's first MFMAs; finished rows go fp32 -> (scale / LeakyReLU)
+//     -> fp16 -> private LDS scratch (transpose) -> 1-KiB buffer stores.  With 32 output channels (4 MFMA waves, 256
+//     VGPRs) the accumulators are double-buffered and block r is drained row by row underneath block r+1's MFMAs.
+//
+// Work decomposition as before: one workgroup = a 16 x 32 pixel block, MFMA wave w owns rows 4*(w&3)..+3, persistent
+// grid (one workgroup per CU) walking an XCD-contiguous, strided list of work items; 4 loader waves only issue
+// LDS-DMA (global_load_lds_dwordx4).  Work-item descriptors are fetched with SCALAR loads (they neither touch the
+// loaders' vmcnt bookkeeping nor need LDS), so a launch never has to be split.
+#include "kernels.h"
+
+namespace rsr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int kFPx = 32;                     // bytes per pixel of a 16-channel plane
+constexpr int kFRow = kPatchW * kFPx;        // 1088 B per patch row
+constexpr int kFPatch = 20 * 1024;           // LDS bytes per patch slot: 20 one-KiB DMA pieces (612 px * 32 B = 19,584 used)
+constexpr int kFPieces = 20;
+constexpr int kFItems = kPatchPx * 2;        // 16-byte items in a patch (1224)
+
+template <int NT>
+struct FlowCfg
+{
+    static constexpr int PR = NT == 1 ? 6 : 4; // patch ring depth (half-stages)
+    static constexpr int WR = 3;               // weight ring depth
+    static constexpr int WB = NT * 9 * 32 * 32; // bytes of one weight image [9 taps][NT*32 cout][16 cin]
+    static constexpr int WPIECES = NT * 9;
+    static constexpr int SCR = 4 * NT * 2048;  // transpose scratch: one 32-px row x 32 cout per (wave, n-tile)
+    static constexpr int W_OFF = PR * kFPatch;
+    static constexpr int SCR_OFF = W_OFF + WR * WB;
+    static constexpr int BIAS_OFF = SCR_OFF + SCR;
+    static constexpr int TOTAL = BIAS_OFF + NT * 128;
+};
+static_assert(FlowCfg<1>::TOTAL <= 160 * 1024 && FlowCfg<2>::TOTAL <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ const char* plane_ptr(const PlaneSrc& s, int slot, int plane)
+{
+    return static_cast<const char*>(s.base) + (long long)slot * s.slot_stride + (long long)plane * s.plane_stride;
+}
+
+// Work-item descriptor through the scalar cache (constant address space => s_load_dwordx8 for a uniform index).
+__device__ __forceinline__ WorkItem load_item(const WorkItem* items, int idx)
+{
+    typedef const __attribute__((address_space(4))) i32x8* cptr_t;
+    const i32x8 v = *(cptr_t)(unsigned long long)(items + idx);
+    WorkItem it;
+    it.slot = __builtin_amdgcn_readfirstlane(v[0]);
+    it.y0 = __builtin_amdgcn_readfirstlane(v[1]);
+    it.x0 = __builtin_amdgcn_readfirstlane(v[2]);
+    it.H = __builtin_amdgcn_readfirstlane(v[3]);
+    it.W = __builtin_amdgcn_readfirstlane(v[4]);
+    it.pad0 = it.pad1 = it.pad2 = 0;
+    return it;
+}
+
+#define RSR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define RSR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+#define RSR_MFMA 0x8
+#define RSR_DSR 0x100
+#define RSR_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+} // namespace
+
+// EPI: 0 generic (conv_last: planar fp16 [3][H][W] output)      1 v = act(acc)  -> fp16 planes
+//      2 v = s1*acc [+ r1 unless it sits in the accumulator as an identity tap] [, v = s2*v + r2] -> fp16 planes
+// NTW: n-tiles (32 output channels) per MFMA wave; the workgroup has 4*NT/NTW MFMA waves + 4 loader waves.
+// DEFER: double-buffered accumulators, block r drained underneath block r+1 (NT == 1 only).
+template <int NT, int NTW, bool UPS, int EPI, bool DEFER>
+__global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) void conv3x3_flow(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef FlowCfg<NT> C;
+    constexpr int MW = 4 * NT / NTW;
+    constexpr int PR = C::PR, WR = C::WR, WB = C::WB;
+    constexpr bool WDB = (NTW == 1); // double-buffered weight fragments (registers to spare with one n-tile per wave)
+    static_assert(!DEFER || (NT == 1 && NTW == 1), "deferred epilogue needs the 256-VGPR budget of the 8-wave workgroup");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nst = a.n0 + a.n1; // half-stages per block (16-channel planes), even by construction (engine pads)
+
+    const int per = (a.nitems + 7) >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    const int first = xcd * per + j;
+    const int end = min((xcd + 1) * per, a.nitems);
+    const int nmine = first < end ? (end - first + nj - 1) / nj : 0;
+    if (nmine == 0) return;
+    const int S = nmine * nst;
+
+    if (tid < NT * 32) reinterpret_cast<float*>(smem + C::BIAS_OFF)[tid] = a.bias[tid];
+    __syncthreads();
+
+    if (wave >= MW)
+    {
+        // ================================ loader waves ================================
+        // Half-stage u = patch P(u) in slot u % PR + weight image W(u) in slot u % WR.  After barrier E_t the MFMA waves
+        // have finished READING half-stage t-1, so the loaders issue W(t+WR-1) and P(t+PR-1), in that order; before
+        // E_t they wait until P(t) and W(t) have landed.  Vector loads retire in order, so with
+        //     ... W(t) P(t+PR-WR) | W(t+1) P(t+PR-WR+1) | ... | W(t+WR-2) P(t+PR-2)      <- issue order, newest right
+        // "s_waitcnt vmcnt(nP + (WR-2)*(nW+nP))" is exactly "W(t) and everything older has landed" (nP, nW = this
+        // wave's pieces per patch / weight image).  Near the end of the work list the tail is shorter: drain fully.
+        const int lw = wave - MW;
+        constexpr int NP = kFPieces / 4; // 5 patch pieces per loader wave
+        const int nW = (C::WPIECES - lw + 3) / 4;
+        int pr[NP], pc[NP], pxor[NP];
+        bool pvalid[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+        {
+            const int jj = (lw + 4 * i) * 64 + lane; // 16-byte item of the patch image, LDS-linear
+            const int px = jj >> 1;
+            pr[i] = px / kPatchW;
+            pc[i] = px - pr[i] * kPatchW;
+            // LDS item jj must receive logical 16-B slot (jj & 1) ^ f(column), f(c) = (c >> 3) & 1 (read-side swizzle)
+            pxor[i] = ((jj & 1) ^ ((pc[i] >> 3) & 1)) << 4;
+            pvalid[i] = jj < kFItems;
+        }
+        const char* wsrc_lane = static_cast<const char*>(a.wpk16) + lw * 1024 + lane * 16;
+
+        int uP = 0, uW = 0, sP = 0, sW = 0, ckP = 0, ckW = 0, rP = 0;
+        WorkItem itP = load_item(a.items, first);
+        unsigned srcoff[NP];
+        auto block_offsets = [&]() {
+            const int H = itP.H, W = itP.W, Wi = UPS ? (W >> 1) : W;
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+            {
+                const int gy = itP.y0 - 1 + pr[i], gx = itP.x0 - 1 + pc[i];
+                const bool ok = pvalid[i] && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const int sy = UPS ? (gy >> 1) : gy, sx = UPS ? (gx >> 1) : gx;
+                srcoff[i] = ok ? unsigned(kGuard + (sy * Wi + sx) * kFPx + pxor[i]) : 0u; // 0 = the plane's zero guard
+            }
+        };
+        block_offsets();
+        auto issueP = [&]() {
+            if (uP >= S) return;
+            const char* gbase = ((ckP < a.n0) ? plane_ptr(a.src0, itP.slot, ckP) : plane_ptr(a.src1, itP.slot, ckP - a.n0)) - kGuard;
+            char* dst = smem + sP * kFPatch + lw * 1024;
+            if (!(a.dbg & 1))
+            {
+#pragma unroll
+                for (int i = 0; i < NP; i++)
+                    __builtin_amdgcn_global_load_lds(RSR_GLB(gbase + srcoff[i]), RSR_LDS(dst + i * 4096), 16, 0, 0);
+            }
+            sP = sP == PR - 1 ? 0 : sP + 1;
+            uP++;
+            if (++ckP == nst)
+            {
+                ckP = 0;
+                if (++rP < nmine)
+                {
+                    itP = load_item(a.items, first + rP * nj);
+                    block_offsets();
+                }
+            }
+        };
+        auto issueW = [&]() {
+            if (uW >= S) return;
+            const char* src = wsrc_lane + (long long)ckW * WB;
+            char* dst = smem + C::W_OFF + sW * WB + lw * 1024;
+            if (!(a.dbg & 1))
+            {
+#pragma unroll
+                for (int i = 0; i < (C::WPIECES + 3) / 4; i++)
+                    if (i < nW)
+                        __builtin_amdgcn_global_load_lds(RSR_GLB(src + i * 4096), RSR_LDS(dst + i * 4096), 16, 0, 0);
+            }
+            sW = sW == WR - 1 ? 0 : sW + 1;
+            uW++;
+            ckW = ckW + 1 == nst ? 0 : ckW + 1;
+        };
+        for (int tt = -(PR - 1); tt < 0; tt++)
+        {
+            if (tt + WR - 1 >= 0) issueW();
+            issueP();
+        }
+        // counted wait immediates: nP + (WR-2)*(nW+nP) with nP = 5, WR = 3
+        constexpr int NW_HI = (C::WPIECES + 3) / 4, NW_LO = C::WPIECES / 4; // loader waves own NW_HI or NW_LO weight pieces
+        for (int t = 0; t < S; t++)
+        {
+            if ((a.dbg & 1) || t + PR - 2 >= S) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (nW == NW_HI) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP + NW_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP + NW_LO) : "memory");
+            issueW();
+            issueP();
+        }
+        asm volatile("s_barrier" ::: "memory"); // E_S: the MFMA waves pass one barrier per half-stage, also in the last one
+        return;
+    }
+
+    // ================================ MFMA waves ================================
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int wrow = wave & 3, ntw0 = (wave >> 2) * NTW;
+    // LDS fragment addresses.  X: patch pixel (r, c) at r*1088 + c*32, its two 16-B slots (k = 0..7 | 8..15) swapped when
+    // (c >> 3) & 1: the 16 lanes of a ds_read_b128 group then cover 16 distinct 16-B bank groups for every tap shift.
+    // One VGPR per dx + immediate row offsets address all fragments.  W: row = tap*NT*32 + n, slots swapped when (n>>3)&1.
+    int xcol[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; dx++)
+    {
+        const int c = l32 + dx;
+        xcol[dx] = wrow * 4 * kFRow + c * kFPx + ((hi ^ ((c >> 3) & 1)) << 4);
+    }
+    const int woff = C::W_OFF + (ntw0 * 32 + l32) * 32 + ((hi ^ ((l32 >> 3) & 1)) << 4);
+
+    // bias in accumulator layout (lane (px, hi), reg q*4+e -> cout q*8 + hi*4 + e): C operand of a block's first MFMAs
+    f32x16 bias16[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; n++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                bias16[n][q * 4 + e] = reinterpret_cast<const float*>(smem + C::BIAS_OFF)[(ntw0 + n) * 32 + q * 8 + hi * 4 + e];
+
+    // transpose scratch of this wave: per n-tile two 16-channel plane rows of 32 px x 32 B; write side (accumulator
+    // layout) lane (px, hi) owns 8 B at px*32 + ((q&1) ^ f(px))*16 + hi*8 of plane q>>1, f(px) = (px>>2)&1;
+    // read side lane (px' = lane>>1, k = lane&1) takes 16 B = channels k*8..+7.
+    char* const scr = smem + C::SCR_OFF + wave * (NTW * 2048);
+    const int scr_w = l32 * 32 + hi * 8, scr_wx = ((l32 >> 2) & 1) << 4;
+    const int rpx = lane >> 1, rk = lane & 1;
+    const int scr_r = rpx * 32 + ((rk ^ ((rpx >> 2) & 1)) << 4);
+
+    const float slope = a.lrelu ? 0.2f : 1.f;
+    const bool idt = (EPI == 2) && a.res1_in_acc && !(a.dbg & 4096);
+    const bool has1 = (EPI == 2) && a.res1_kind == 1 && !idt;
+    const bool has2 = (EPI == 2) && a.res2_kind == 1;
+#ifdef RSR_FLOW_TRACE // experiment builds only: an s_memtime in the loop forces every lgkmcnt wait to 0 (SMEM returns out of order)
+    const bool tracing = a.trace && blockIdx.x == 0 && wave == 0;
+#else
+    constexpr bool tracing = false;
+#endif
+
+    float pinf0 = __builtin_inff();
+    asm volatile("" : "+s"(pinf0)); // opaque +inf: see the deferred epilogue
+
+    // ---- epilogue pieces ----
+    struct OutDesc
+    {
+        char* base; // plane 2*ntw0 of the output slot
+        int live;   // 0: stores are dropped (null resource)
+        int voff;   // lane's byte offset inside a plane row (or the out-of-range sentinel)
+        int y0, H, W, x0, slot;
+    };
+    auto make_out = [&](const WorkItem& it, bool live) {
+        OutDesc o;
+        o.base = const_cast<char*>(plane_ptr(a.out16, it.slot, ntw0 * 2));
+        o.live = (live && !(a.dbg & 4)) ? 1 : 0;
+        const int x = it.x0 + rpx;
+        o.voff = x < it.W ? x * kFPx + rk * 16 : int(0x80000000u);
+        o.y0 = it.y0 + wrow * 4;
+        o.H = it.H;
+        o.W = it.W;
+        o.x0 = it.x0;
+        o.slot = it.slot;
+        return o;
+    };
+    // one finished row (32 px x 32 cout of n-tile n): scale / LeakyReLU, fp16, transpose-write into the scratch
+    auto row_to_lds = [&](const f32x16& acc, int n) {
+        char* wr = scr + n * 2048 + scr_w;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                float v = acc[q * 4 + e];
+                if (EPI == 2) v = v * a.s1;
+                else v = __builtin_amdgcn_fmed3f(v, v * slope, pinf0); // = max(v, slope*v), one instruction
+                o[e] = (_Float16)v;
+            }
+            *reinterpret_cast<half4*>(wr + (q >> 1) * 1024 + (((q & 1) << 4) ^ scr_wx)) = o;
+        }
+    };
+    auto row_from_lds = [&](u32x4 (&tq)[2], int n) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) tq[p] = *reinterpret_cast<const u32x4*>(scr + n * 2048 + p * 1024 + scr_r);
+    };
+    // residual stages in the transposed domain (lane = 8 consecutive channels of one pixel): v = t + r1, v = v*s2 + r2
+    auto row_residual = [&](u32x4 (&tq)[2], const OutDesc& o, int rr, int n) {
+        if (!(has1 || has2)) return;
+        const int y = o.y0 + rr, x = o.x0 + rpx;
+        const bool ok = y < o.H && x < o.W;
+        const long long off = ((long long)y * o.W + x) * kFPx + rk * 16;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+        {
+            half8 r1 = {0, 0, 0, 0, 0, 0, 0, 0}, r2 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (has1 && ok) r1 = *reinterpret_cast<const half8*>(plane_ptr(a.res1, o.slot, (ntw0 + n) * 2 + p) + off);
+            if (has2 && ok) r2 = *reinterpret_cast<const half8*>(plane_ptr(a.res2, o.slot, (ntw0 + n) * 2 + p) + off);
+            half8 v = __builtin_bit_cast(half8, tq[p]);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+            {
+                float f = (float)v[e];
+                if (has1) f += (float)r1[e];
+                if (has2) f = f * a.s2 + (float)r2[e];
+                v[e] = (_Float16)f;
+            }
+            tq[p] = __builtin_bit_cast(u32x4, v);
+        }
+    };
+    // 1 KiB per store instruction: 32 pixels x 32 B of one 16-channel plane row; rows / columns outside the image are
+    // dropped by the buffer range check (null resource / out-of-range offset), so the epilogue is branch-free
+    auto row_store = [&](const u32x4 (&tq)[2], const OutDesc& o, int rr, int n) {
+        const int y = o.y0 + rr;
+        const unsigned long long b = (unsigned long long)o.base;
+        char* ub = reinterpret_cast<char*>((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)b) |
+                                           ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
+        const unsigned pstride = unsigned(a.out16.plane_stride);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            __builtin_amdgcn_raw_buffer_store_b128(tq[p], rs, o.voff, unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride, 0);
+    };
+    // conv_last (EPI 0): channels 0..2 of n-tile 0 -> planar fp16 [3][H][W]
+    auto planar_store = [&](const f32x16 (&acc)[4][NTW], const WorkItem& it) {
+        if (hi != 0 || ntw0 != 0 || (a.dbg & 4)) return;
+        _Float16* o = reinterpret_cast<_Float16*>(static_cast<char*>(a.out_planar3) + (long long)it.slot * a.planar3_slot_stride);
+        const long long hw = (long long)it.H * it.W;
+        const int x = it.x0 + l32;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+        {
+            const int y = it.y0 + wrow * 4 + rr;
+            if (y < it.H && x < it.W)
+            {
+                const long long pix = (long long)y * it.W + x;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    float v = acc[rr][0][ch];
+                    if (a.lrelu) v = fmaxf(v, v * 0.2f);
+                    o[ch * hw + pix] = (_Float16)v;
+                }
+            }
+        }
+    };
+
+    // ---- operand fragments, accumulators ----
+    half8 X[6], Wa[3][NTW], Wb[WDB ? 3 : 1][NTW];
+    f32x16 accA[4][NTW], accB[DEFER ? 4 : 1][NTW];
+
+    int sP = 0, sW = 0; // ring slots of the half-stage being multiplied
+    int r = 0, ck = 0, t = 0;
+    auto xbase = [&](int slot, int dx) { return smem + slot * kFPatch + xcol[dx]; };
+    auto wbase = [&](int slot) { return smem + slot * WB + woff; };
+#define RSR_LDX(R, XB) X[R] = *reinterpret_cast<const half8*>((XB) + (R)*kFRow);
+#define RSR_LDW(WS, DY, DX, WBASE)                                                                                   \
+    _Pragma("unroll") for (int n_ = 0; n_ < NTW; n_++) WS[DY][n_] =                                                  \
+        *reinterpret_cast<const half8*>((WBASE) + ((DY)*3 + (DX)) * (NT * 1024) + n_ * 1024);
+#define RSR_CELL(ACC, WS, DY, RR, FIRST)                                                                             \
+    _Pragma("unroll") for (int n_ = 0; n_ < NTW; n_++) ACC[RR][n_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(         \
+        WS[DY][n_], X[(RR) + (DY)], ((FIRST) && (DY) == 0) ? bias16[n_] : ACC[RR][n_], 0, 0, 0);
+#define RSR_NOHK(c)
+
+    // One (dx) step = 12 cells (dy, rr) in anti-diagonal order; the fragments of the NEXT step (NXB / NWB: their LDS
+    // bases, NDX its dx) are reloaded in place as soon as the diagonal that last reads them has been issued.  BAR: the
+    // dx = 2 step of a half-stage -- once the first three cells are issued every LDS read of the half-stage has had > 100
+    // cycles to return, the wave passes the barrier ("my reads of this half-stage are done" / "the next one has landed")
+    // and only then touches the next half-stage's slots.  WCUR / WNXT: weight fragment sets (the same array when !WDB).
+    // HK(c): work of the deferred epilogue that rides behind cell c (fenced, so it stays there).
+    // ITEMQ: also fetch the descriptor of the block after next -- a scalar load the COMPILER must not see (a visible SMEM
+    // load turns every counted lgkmcnt wait behind it into lgkmcnt(0)); it lands under the three cells in front of the
+    // barrier and is covered by the barrier's own lgkmcnt(0).  (The compiler's counted DS waits in between stay safe: the
+    // hidden load can only make them over-wait by one.)
+#define RSR_STEP(ACC, WCUR, WNXT, NXB, NWB, NDX, FIRST, BAR, ITEMQ, HK)                                              \
+    {                                                                                                                \
+        if ((BAR) && (ITEMQ))                                                                                        \
+        {                                                                                                            \
+            const WorkItem* ip_ = a.items + (first + min(r + 2, nmine - 1) * nj);                                    \
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(item_q) : "s"(ip_));                                    \
+        }                                                                                                            \
+        RSR_CELL(ACC, WCUR, 0, 0, FIRST) HK(0)                                                                       \
+        if (!(BAR)) { RSR_LDX(0, NXB) if (WDB) { RSR_LDW(WNXT, 0, NDX, NWB) } }                                      \
+        RSR_CELL(ACC, WCUR, 0, 1, FIRST) HK(1) RSR_CELL(ACC, WCUR, 1, 0, FIRST) HK(2)                                \
+        if (BAR)                                                                                                     \
+        {                                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            if (tracing) t_arr = __builtin_amdgcn_s_memtime();                                                       \
+            if (ITEMQ) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(item_q)::"memory");                   \
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            RSR_LDX(0, NXB) if (WDB) { RSR_LDW(WNXT, 0, NDX, NWB) }                                                  \
+        }                                                                                                            \
+        RSR_LDX(1, NXB) if (WDB) { RSR_LDW(WNXT, 1, NDX, NWB) }                                                      \
+        RSR_CELL(ACC, WCUR, 0, 2, FIRST) HK(3) RSR_CELL(ACC, WCUR, 1, 1, FIRST) HK(4) RSR_CELL(ACC, WCUR, 2, 0, FIRST) HK(5) \
+        RSR_LDX(2, NXB) if (WDB) { RSR_LDW(WNXT, 2, NDX, NWB) }                                                      \
+        RSR_CELL(ACC, WCUR, 0, 3, FIRST) HK(6)                                                                       \
+        if (!WDB) { RSR_LDW(WNXT, 0, NDX, NWB) }                                                                     \
+        RSR_CELL(ACC, WCUR, 1, 2, FIRST) HK(7) RSR_CELL(ACC, WCUR, 2, 1, FIRST) HK(8)                                \
+        RSR_LDX(3, NXB)                                                                                              \
+        RSR_CELL(ACC, WCUR, 1, 3, FIRST) HK(9)                                                                       \
+        if (!WDB) { RSR_LDW(WNXT, 1, NDX, NWB) }                                                                     \
+        RSR_CELL(ACC, WCUR, 2, 2, FIRST) HK(10)                                                                      \
+        RSR_LDX(4, NXB)                                                                                              \
+        RSR_CELL(ACC, WCUR, 2, 3, FIRST) HK(11)                                                                      \
+        RSR_LDX(5, NXB)                                                                                              \
+        if (!WDB) { RSR_LDW(WNXT, 2, NDX, NWB) }                                                                     \
+    }
+    // Issue-order pins for a step without hooks (MFMA / DS-read group sizes follow RSR_STEP; a BAR step is split by the
+    // barrier).  Steps with hooks are pinned by the hooks' fences instead (PIN = 0).
+#define RSR_STEP_SCHED(BAR, PIN)                                                                                     \
+    if (PIN)                                                                                                         \
+    {                                                                                                                \
+        if (BAR)                                                                                                     \
+        {                                                                                                            \
+            RSR_SG(RSR_DSR, WDB ? 4 : 2);                                                                            \
+            RSR_SG(RSR_MFMA, 3 * NTW); RSR_SG(RSR_DSR, WDB ? 2 : 1);                                                 \
+        }                                                                                                            \
+        else                                                                                                         \
+        {                                                                                                            \
+            RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, WDB ? 2 : 1);                                                 \
+            RSR_SG(RSR_MFMA, 2 * NTW); RSR_SG(RSR_DSR, WDB ? 2 : 1);                                                 \
+            RSR_SG(RSR_MFMA, 3 * NTW); RSR_SG(RSR_DSR, WDB ? 2 : 1);                                                 \
+        }                                                                                                            \
+        if (WDB)                                                                                                     \
+        {                                                                                                            \
+            RSR_SG(RSR_MFMA, 3); RSR_SG(RSR_DSR, 1);                                                                 \
+            RSR_SG(RSR_MFMA, 2); RSR_SG(RSR_DSR, 1);                                                                 \
+            RSR_SG(RSR_MFMA, 1); RSR_SG(RSR_DSR, 1);                                                                 \
+        }                                                                                                            \
+        else                                                                                                         \
+        {                                                                                                            \
+            RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, NTW);                                                         \
+            RSR_SG(RSR_MFMA, 2 * NTW); RSR_SG(RSR_DSR, 1);                                                           \
+            RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, NTW);                                                         \
+            RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, 1);                                                           \
+            RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, 1 + NTW);                                                     \
+        }                                                                                                            \
+    }
+    // Identity tap: out = s1*(conv + b) + x with x = this conv's own input planes 2*nt, 2*nt+1 (RDB conv5, fp16 trunk):
+    // while that plane is the current half-stage, acc += (1/s1)*x on the matrix pipe (A = coef*I on the plane's 16
+    // output channels, B = the centre-tap pixels) -- the epilogue has no residual to fetch.  Runs after the half-stage's
+    // first step (every accumulator row is initialised by then) and before its dx = 2 step hands the slot back.
+#define RSR_IDTAP(ACC)                                                                                               \
+    if (EPI == 2 && idt)                                                                                             \
+    {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int n_ = 0; n_ < NTW; n_++) if ((ck >> 1) == ntw0 + n_)                               \
+        {                                                                                                            \
+            half8 idf;                                                                                               \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) idf[e] =                                                   \
+                ((ck & 1) * 16 + hi * 8 + e == l32) ? (_Float16)a.res1_coef : (_Float16)0.f;                         \
+            const char* cb_ = xbase(sP, 1);                                                                          \
+            _Pragma("unroll") for (int rr = 0; rr < 4; rr++)                                                         \
+            {                                                                                                        \
+                const half8 xc = *reinterpret_cast<const half8*>(cb_ + (rr + 1) * kFRow);                            \
+                ACC[rr][n_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf, xc, ACC[rr][n_], 0, 0, 0);                 \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+    // one half-stage (3 steps) on accumulators ACC; W0 holds the dx = 0 fragments (sets alternate per step when WDB);
+    // HK0..2: hook macros of the three steps (RSR_NOHK = none, the step is then pinned by RSR_STEP_SCHED)
+#define RSR_HALF(ACC, W0, W1, FIRST, HK0, P0, HK1, P1, HK2, P2)                                                      \
+    {                                                                                                                \
+        const int nsP = sP == PR - 1 ? 0 : sP + 1, nsW = sW == WR - 1 ? 0 : sW + 1;                                  \
+        {                                                                                                            \
+            const char* nxb = xbase(sP, 1);                                                                          \
+            const char* nwb = wbase(sW);                                                                             \
+            RSR_STEP(ACC, W0, W1, nxb, nwb, 1, FIRST, false, false, HK0)                                             \
+            RSR_STEP_SCHED(false, P0)                                                                                \
+        }                                                                                                            \
+        RSR_IDTAP(ACC)                                                                                               \
+        {                                                                                                            \
+            const char* nxb = xbase(sP, 2);                                                                          \
+            const char* nwb = wbase(sW);                                                                             \
+            RSR_STEP(ACC, W1, W0, nxb, nwb, 2, false, false, false, HK1)                                             \
+            RSR_STEP_SCHED(false, P1)                                                                                \
+        }                                                                                                            \
+        {                                                                                                            \
+            const char* nxb = xbase(nsP, 0);                                                                         \
+            const char* nwb = wbase(nsW);                                                                            \
+            RSR_STEP(ACC, W0, W1, nxb, nwb, 0, false, true, FIRST, HK2)                                              \
+            RSR_STEP_SCHED(true, P2)                                                                                 \
+        }                                                                                                            \
+        if (tracing && lane == 0 && t + 1 < 512)                                                                     \
+        {                                                                                                            \
+            a.trace[2 * (t + 1)] = t_arr;                                                                            \
+            a.trace[2 * (t + 1) + 1] = __builtin_amdgcn_s_memtime();                                                 \
+        }                                                                                                            \
+        sP = nsP;                                                                                                    \
+        sW = nsW;                                                                                                    \
+        t++;                                                                                                         \
+    }
+#define RSR_HALF_PLAIN(ACC, W0, W1, FIRST) RSR_HALF(ACC, W0, W1, FIRST, RSR_NOHK, 1, RSR_NOHK, 1, RSR_NOHK, 1)
+
+    WorkItem it = load_item(a.items, first);
+    WorkItem nxt = load_item(a.items, first + (nmine > 1 ? nj : 0));
+    i32x8 item_q = {0, 0, 0, 0, 0, 0, 0, 0}; // descriptor of block r+2, fetched during block r's first half-stage
+    auto item_from_q = [&]() {
+        WorkItem w;
+        w.slot = item_q[0]; w.y0 = item_q[1]; w.x0 = item_q[2]; w.H = item_q[3]; w.W = item_q[4];
+        w.pad0 = w.pad1 = w.pad2 = 0;
+        return w;
+    };
+
+    unsigned long long t_arr = 0;
+    if (tracing) t_arr = __builtin_amdgcn_s_memtime();
+    asm volatile("s_barrier" ::: "memory"); // E_0: half-stage 0 is in LDS
+    if (tracing && lane == 0)
+    {
+        a.trace[0] = t_arr;
+        a.trace[1] = __builtin_amdgcn_s_memtime();
+    }
+    {
+        const char* xb = xbase(0, 0);
+        const char* wb = wbase(0);
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) { RSR_LDX(rr, xb) }
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) { RSR_LDW(Wa, dy, 0, wb) }
+    }
+
+    if (!DEFER)
+    {
+        for (r = 0; r < nmine; r++)
+        {
+            for (int cp = 0; cp < nst; cp += 2)
+            {
+                ck = cp;
+                if (WDB)
+                {
+                    if (cp == 0) { RSR_HALF_PLAIN(accA, Wa, Wb, true) }
+                    else { RSR_HALF_PLAIN(accA, Wa, Wb, false) }
+                    ck = cp + 1;
+                    RSR_HALF_PLAIN(accA, Wb, Wa, false)
+                }
+                else
+                {
+                    if (cp == 0) { RSR_HALF_PLAIN(accA, Wa, Wa, true) }
+                    else { RSR_HALF_PLAIN(accA, Wa, Wa, false) }
+                    ck = cp + 1;
+                    RSR_HALF_PLAIN(accA, Wa, Wa, false)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- epilogue of block r (the fragments of block r+1's first step are already in registers) ----
+            if (EPI == 0) planar_store(accA, it);
+            else
+            {
+                const OutDesc o = make_out(it, true);
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+                {
+#pragma unroll
+                    for (int n = 0; n < NTW; n++) row_to_lds(accA[rr][n], n);
+#pragma unroll
+                    for (int n = 0; n < NTW; n++)
+                    {
+                        u32x4 tq[2];
+                        row_from_lds(tq, n);
+                        if (EPI == 2) row_residual(tq, o, rr, n);
+                        row_store(tq, o, rr, n);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            it = nxt;
+            nxt = item_from_q();
+        }
+    }
+    else
+    {
+        // ---- deferred epilogue (32 output channels, 4 MFMA waves): block r accumulates into one accumulator set while
+        // the other set, holding block r-1, is drained during block r's first five steps.  The work is cut into pieces
+        // of ~5 instructions that ride behind individual MFMA cells (fenced in place): step k converts row k (per value
+        // pair: LeakyReLU = med3(v, slope*v, +inf), fp16 pack; per quad one ds_write_b64 into the transpose scratch),
+        // step k+1 reads the row back transposed (2 ds_read_b128) and stores it (2 x 1 KiB).  The first block drains
+        // its uninitialised partner set into a null resource.
+        OutDesc od = make_out(it, false);
+        u32x4 tq[2];
+        half2v pk[4][2];
+        float pinf = __builtin_inff();
+        asm volatile("" : "+s"(pinf)); // opaque: med3(v, s*v, +inf) stays ONE instruction (a literal folds to maxnum + canonicalize)
+        auto row_store1 = [&](const u32x4& v, const OutDesc& o, int rr, int p) {
+            const int y = o.y0 + rr;
+            const unsigned long long b = (unsigned long long)o.base;
+            char* ub = reinterpret_cast<char*>((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)b) |
+                                               ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, o.voff, unsigned(y) * unsigned(o.W * kFPx) + unsigned(p) * unsigned(a.out16.plane_stride), 0);
+        };
+#define RSR_HK_S0(c) RSR_HK_S0_##c
+#define RSR_HK_S0_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][0], v1_ = RSR_OLD[0][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][2], v1_ = RSR_OLD[0][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][4], v1_ = RSR_OLD[0][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][6], v1_ = RSR_OLD[0][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][8], v1_ = RSR_OLD[0][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][10], v1_ = RSR_OLD[0][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][12], v1_ = RSR_OLD[0][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][14], v1_ = RSR_OLD[0][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_11 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1(c) RSR_HK_S1_##c
+#define RSR_HK_S1_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][0], v1_ = RSR_OLD[1][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][2], v1_ = RSR_OLD[1][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][4], v1_ = RSR_OLD[1][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][6], v1_ = RSR_OLD[1][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][8], v1_ = RSR_OLD[1][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][10], v1_ = RSR_OLD[1][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][12], v1_ = RSR_OLD[1][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][14], v1_ = RSR_OLD[1][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 0, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 0, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2(c) RSR_HK_S2_##c
+#define RSR_HK_S2_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][0], v1_ = RSR_OLD[2][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][2], v1_ = RSR_OLD[2][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][4], v1_ = RSR_OLD[2][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][6], v1_ = RSR_OLD[2][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][8], v1_ = RSR_OLD[2][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][10], v1_ = RSR_OLD[2][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][12], v1_ = RSR_OLD[2][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][14], v1_ = RSR_OLD[2][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 1, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 1, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3(c) RSR_HK_S3_##c
+#define RSR_HK_S3_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][0], v1_ = RSR_OLD[3][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][2], v1_ = RSR_OLD[3][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][4], v1_ = RSR_OLD[3][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][6], v1_ = RSR_OLD[3][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][8], v1_ = RSR_OLD[3][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][10], v1_ = RSR_OLD[3][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][12], v1_ = RSR_OLD[3][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][14], v1_ = RSR_OLD[3][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 2, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 2, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4(c) RSR_HK_S4_##c
+#define RSR_HK_S4_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_1 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_3 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_5 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_7 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_9 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 3, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 3, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_BLOCK(ACC)                                                                                               \
+    {                                                                                                                \
+        ck = 0;                                                                                                      \
+        RSR_HALF(ACC, Wa, Wb, true, RSR_HK_S0, 0, RSR_HK_S1, 0, RSR_HK_S2, 0)                                        \
+        ck = 1;                                                                                                      \
+        RSR_HALF(ACC, Wb, Wa, false, RSR_HK_S3, 0, RSR_HK_S4, 0, RSR_NOHK, 1)                                        \
+        for (int cp = 2; cp < nst; cp += 2)                                                                          \
+        {                                                                                                            \
+            ck = cp;                                                                                                 \
+            RSR_HALF_PLAIN(ACC, Wa, Wb, false)                                                                       \
+            ck = cp + 1;                                                                                             \
+            RSR_HALF_PLAIN(ACC, Wb, Wa, false)                                                                       \
+        }                                                                                                            \
+        od = make_out(it, true);                                                                                     \
+        it = nxt;                                                                                                    \
+        nxt = item_from_q();                                                                                         \
+    }
+        for (r = 0; r < nmine; r += 2)
+        {
+#define RSR_OLD accB
+            RSR_BLOCK(accA)
+#undef RSR_OLD
+            if (r + 1 < nmine)
+            {
+                r++;
+#define RSR_OLD accA
+                RSR_BLOCK(accB)
+#undef RSR_OLD
+                r--;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // drain the last block
+        if (nmine & 1)
+        {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+            {
+                row_to_lds(accA[rr][0], 0);
+                row_from_lds(tq, 0);
+                row_store(tq, od, rr, 0);
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+            {
+                row_to_lds(accB[rr][0], 0);
+                row_from_lds(tq, 0);
+                row_store(tq, od, rr, 0);
+            }
+        }
+#undef RSR_BLOCK
+#undef RSR_HK_S0
+#undef RSR_HK_S0_0
+#undef RSR_HK_S0_1
+#undef RSR_HK_S0_2
+#undef RSR_HK_S0_3
+#undef RSR_HK_S0_4
+#undef RSR_HK_S0_5
+#undef RSR_HK_S0_6
+#undef RSR_HK_S0_7
+#undef RSR_HK_S0_8
+#undef RSR_HK_S0_9
+#undef RSR_HK_S0_10
+#undef RSR_HK_S0_11
+#undef RSR_HK_S1
+#undef RSR_HK_S1_0
+#undef RSR_HK_S1_1
+#undef RSR_HK_S1_2
+#undef RSR_HK_S1_3
+#undef RSR_HK_S1_4
+#undef RSR_HK_S1_5
+#undef RSR_HK_S1_6
+#undef RSR_HK_S1_7
+#undef RSR_HK_S1_8
+#undef RSR_HK_S1_9
+#undef RSR_HK_S1_10
+#undef RSR_HK_S1_11
+#undef RSR_HK_S2
+#undef RSR_HK_S2_0
+#undef RSR_HK_S2_1
+#undef RSR_HK_S2_2
+#undef RSR_HK_S2_3
+#undef RSR_HK_S2_4
+#undef RSR_HK_S2_5
+#undef RSR_HK_S2_6
+#undef RSR_HK_S2_7
+#undef RSR_HK_S2_8
+#undef RSR_HK_S2_9
+#undef RSR_HK_S2_10
+#undef RSR_HK_S2_11
+#undef RSR_HK_S3
+#undef RSR_HK_S3_0
+#undef RSR_HK_S3_1
+#undef RSR_HK_S3_2
+#undef RSR_HK_S3_3
+#undef RSR_HK_S3_4
+#undef RSR_HK_S3_5
+#undef RSR_HK_S3_6
+#undef RSR_HK_S3_7
+#undef RSR_HK_S3_8
+#undef RSR_HK_S3_9
+#undef RSR_HK_S3_10
+#undef RSR_HK_S3_11
+#undef RSR_HK_S4
+#undef RSR_HK_S4_0
+#undef RSR_HK_S4_1
+#undef RSR_HK_S4_2
+#undef RSR_HK_S4_3
+#undef RSR_HK_S4_4
+#undef RSR_HK_S4_5
+#undef RSR_HK_S4_6
+#undef RSR_HK_S4_7
+#undef RSR_HK_S4_8
+#undef RSR_HK_S4_9
+#undef RSR_HK_S4_10
+#undef RSR_HK_S4_11
+    }
+#undef RSR_HALF_PLAIN
+#undef RSR_HALF
+#undef RSR_IDTAP
+#undef RSR_STEP
+#undef RSR_STEP_SCHED
+#undef RSR_CELL
+#undef RSR_LDX
+#undef RSR_LDW
+#undef RSR_NOHK
+}
+
+// ---- launch ------------------------------------------------------------------------------------
+template <int NT, int NTW, bool UPS, int EPI, bool DEFER>
+static hipError_t flow_attr()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_flow<NT, NTW, UPS, EPI, DEFER>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, FlowCfg<NT>::TOTAL);
+}
+
+template <int NT, int NTW, bool UPS, int EPI, bool DEFER>
+static void flow_launch(const ConvArgs& a, int ncu, hipStream_t st)
+{
+    int grid = ncu & ~7;
+    const int per = (a.nitems + 7) / 8;
+    if (per * 8 < grid) grid = per * 8;
+    hipLaunchKernelGGL((conv3x3_flow<NT, NTW, UPS, EPI, DEFER>), dim3(grid), dim3((4 * NT / NTW + 4) * 64), FlowCfg<NT>::TOTAL, st, a);
+}
+
+// every instantiation the engine can reach, for the per-device opt-in to > 64 KiB of dynamic LDS
+#define RSR_FLOW_VARIANTS(F)                                                                                         \
+    F(1, 1, false, 0, false) F(1, 1, false, 1, false) F(1, 1, false, 1, true) F(1, 1, false, 2, false)               \
+    F(1, 1, true, 1, false)                                                                                          \
+    F(2, 1, false, 1, false) F(2, 1, false, 2, false) F(2, 1, true, 1, false)                                        \
+    F(2, 2, false, 1, false) F(2, 2, false, 2, false) F(2, 2, true, 1, false)
+
+hipError_t flow_init_device()
+{
+    hipError_t e = hipSuccess;
+#define RSR_F(NT, NTW, UPS, EPI, DEFER)                                                                              \
+    if (e == hipSuccess) e = flow_attr<NT, NTW, UPS, EPI, DEFER>();
+    RSR_FLOW_VARIANTS(RSR_F)
+#undef RSR_F
+    return e;
+}
+
+// flags: bit 0 = two n-tiles per MFMA wave for the 64-output-channel convs (4 MFMA waves), bit 1 = no deferred epilogue
+bool launch_conv_flow(const ConvArgs& a, int nt, int ncu, int flags, hipStream_t st)
+{
+    if (a.nitems <= 0) return true;
+    if (((a.n0 + a.n1) & 1) || !a.wpk16) return false;
+    const bool ups = a.lvl_out != a.lvl_in;
+    int epi = 0;
+    if (a.out16.base && !a.out32a.base && !a.out32b.base && !a.out_planar3)
+    {
+        if (a.res1_kind == 0 && a.res2_kind == 0) epi = 1;
+        else if (a.res1_kind == 1 && (a.res2_kind == 0 || a.res2_kind == 1)) epi = 2;
+        else return false;
+    }
+    else if (!a.out_planar3 || a.out16.base || a.out32a.base || a.out32b.base || a.res1_kind || a.res2_kind) return false;
+    const bool ntw2 = (flags & 1) != 0, defer = !(flags & 2);
+    if (nt == 1)
+    {
+        if (epi == 0 && !ups) flow_launch<1, 1, false, 0, false>(a, ncu, st);
+        else if (epi == 1 && !ups && defer) flow_launch<1, 1, false, 1, true>(a, ncu, st);
+        else if (epi == 1 && !ups) flow_launch<1, 1, false, 1, false>(a, ncu, st);
+        else if (epi == 1) flow_launch<1, 1, true, 1, false>(a, ncu, st);
+        else if (epi == 2 && !ups) flow_launch<1, 1, false, 2, false>(a, ncu, st);
+        else return false;
+        return true;
+    }
+    if (nt != 2 || epi == 0) return false;
+    if (ntw2)
+    {
+        if (epi == 1 && !ups) flow_launch<2, 2, false, 1, false>(a, ncu, st);
+        else if (epi == 1) flow_launch<2, 2, true, 1, false>(a, ncu, st);
+        else if (!ups) flow_launch<2, 2, false, 2, false>(a, ncu, st);
+        else return false;
+    }
+    else
+    {
+        if (epi == 1 && !ups) flow_launch<2, 1, false, 1, false>(a, ncu, st);
+        else if (epi == 1) flow_launch<2, 1, true, 1, false>(a, ncu, st);
+        else if (!ups) flow_launch<2, 1, false, 2, false>(a, ncu, st);
+        else return false;
+    }
+    return true;
+}
+
+} // namespace rsr

@@ -7,6 +7,9 @@
 
 namespace rsr {
 
+static thread_local std::string tl_err;
+const char* last_error() { return tl_err.c_str(); }
+
 #define HIP_TRY(expr)                                                                              \
     do                                                                                             \
     {                                                                                              \
@@ -16,19 +19,31 @@ namespace rsr {
 
 int Engine::fail(int code, const std::string& msg)
 {
-    err = msg;
+    tl_err = msg;
     return code;
 }
 
 Engine::~Engine()
 {
     if (device >= 0) (void)hipSetDevice(device);
-    free_plan();
-    DevBuf* all[] = {&blob, &zeros, &b_in, &b_fea, &b_rdb[0], &b_rdb[1], &b_rdb[2], &b_t32, &b_r32,
-                     &b_up1, &b_up2, &b_hr, &b_out3, &d_img_in, &d_img_out};
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& l : lanes)
+    {
+        if (l->copy) (void)hipStreamSynchronize(l->copy);
+        if (l->d_in.p) (void)hipFree(l->d_in.p);
+        if (l->d_out.p) (void)hipFree(l->d_out.p);
+        if (l->h_in) (void)hipHostFree(l->h_in);
+        if (l->h_out) (void)hipHostFree(l->h_out);
+        for (hipEvent_t e : {l->ev_in, l->ev_done, l->ev_chunk[0], l->ev_chunk[1]})
+            if (e) (void)hipEventDestroy(e);
+        if (l->copy) (void)hipStreamDestroy(l->copy);
+    }
+    free_plans();
+    DevBuf* all[] = {&blob, &zeros, &b_in, &b_fea, &b_rdb[0], &b_rdb[1], &b_rdb[2], &b_t32, &b_r32, &b_up1, &b_up2, &b_hr, &b_out3, &trace_buf};
     for (DevBuf* b : all)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : sync_events) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -46,6 +61,7 @@ int Engine::init(int gpuid, int tta_mode)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RSR_E_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(kernels_init_device()); // per-device opt-in to > 64 KiB dynamic LDS for every kernel instantiation
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&zeros.p, 256));
     zeros.bytes = 256;
@@ -54,12 +70,13 @@ int Engine::init(int gpuid, int tta_mode)
     return RSR_OK;
 }
 
+// Grow-only device buffer.  Growing frees the old allocation: the caller guarantees nothing in flight uses it
+// (workspace: the compute stream is drained first; lane buffers: the lane is owned by the caller).
 int Engine::ensure(DevBuf& b, size_t bytes)
 {
     if (b.bytes >= bytes && b.p) return RSR_OK;
     if (b.p)
     {
-        HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(b.p);
         b.p = nullptr;
         b.bytes = 0;
@@ -68,25 +85,62 @@ int Engine::ensure(DevBuf& b, size_t bytes)
     if (e != hipSuccess)
     {
         b.p = nullptr;
+        (void)hipGetLastError();
         return fail(RSR_E_NOMEM, "hipMalloc(" + std::to_string(bytes) + ") failed: " + hipGetErrorString(e));
     }
     b.bytes = bytes;
     return RSR_OK;
 }
 
+hipEvent_t Engine::take_event()
+{
+    if (!sync_events.empty())
+    {
+        hipEvent_t e = sync_events.back();
+        sync_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+
+void Engine::give_event(hipEvent_t e)
+{
+    if (e) sync_events.push_back(e);
+}
+
 // ---- model --------------------------------------------------------------------------------
-int Engine::load_blob_host(const void* data, size_t bytes)
+int Engine::adopt_table(const unsigned char* head, size_t bytes)
 {
     std::string e;
-    int rc = check_packed(data, bytes, e);
+    const int rc = check_packed(head, packed_table_bytes(), bytes, e);
     if (rc != RSR_OK) return fail(rc, e);
-    HIP_TRY(hipSetDevice(device));
-    rc = ensure(blob, bytes);
+    return RSR_OK;
+}
+
+int Engine::load_blob_host(const void* data, size_t bytes)
+{
+    if (!data || bytes < packed_table_bytes()) return fail(RSR_E_FORMAT, "packed blob too small");
+    // validate BEFORE touching engine state: a failed load leaves a previously loaded model intact
+    int rc = adopt_table(static_cast<const unsigned char*>(data), bytes);
     if (rc != RSR_OK) return rc;
-    HIP_TRY(hipMemcpy(blob.p, data, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize(stream));
+    DevBuf fresh;
+    if ((rc = ensure(fresh, bytes)) != RSR_OK) return rc;
+    hipError_t he = hipMemcpy(fresh.p, data, bytes, hipMemcpyHostToDevice);
+    if (he != hipSuccess)
+    {
+        (void)hipFree(fresh.p);
+        return fail(RSR_E_DEVICE, std::string("blob upload: ") + hipGetErrorString(he));
+    }
+    if (blob.p) (void)hipFree(blob.p);
+    blob = fresh;
     const PackedHeader* H = static_cast<const PackedHeader*>(data);
     const PackedConv* T = reinterpret_cast<const PackedConv*>(static_cast<const unsigned char*>(data) + sizeof(PackedHeader));
     convs.assign(T, T + H->nconv);
+    has_w32 = (H->flags & 1u) != 0;
     loaded = true;
     return RSR_OK;
 }
@@ -94,22 +148,27 @@ int Engine::load_blob_host(const void* data, size_t bytes)
 int Engine::load_blob_device(const void* data, size_t bytes)
 {
     // header + table are small: fetch them to the host for validation, keep the payload on device
-    if (bytes < sizeof(PackedHeader)) return fail(RSR_E_FORMAT, "packed blob too small");
+    if (!data || bytes < packed_table_bytes()) return fail(RSR_E_FORMAT, "packed blob too small");
     HIP_TRY(hipSetDevice(device));
-    std::vector<unsigned char> head(sizeof(PackedHeader) + size_t(kNumConvs) * sizeof(PackedConv));
-    if (bytes < head.size()) return fail(RSR_E_FORMAT, "packed blob too small");
+    std::vector<unsigned char> head(packed_table_bytes());
     HIP_TRY(hipMemcpy(head.data(), data, head.size(), hipMemcpyDeviceToHost));
-    const PackedHeader* H = reinterpret_cast<const PackedHeader*>(head.data());
-    if (H->magic != kPackedMagic || H->version != 2 || H->nconv != uint32_t(kNumConvs) || H->total_bytes != bytes)
-        return fail(RSR_E_FORMAT, "packed blob header mismatch");
-    int rc = ensure(blob, bytes);
+    int rc = adopt_table(head.data(), bytes);
     if (rc != RSR_OK) return rc;
-    HIP_TRY(hipMemcpy(blob.p, data, bytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipStreamSynchronize(stream));
+    DevBuf fresh;
+    if ((rc = ensure(fresh, bytes)) != RSR_OK) return rc;
+    hipError_t he = hipMemcpy(fresh.p, data, bytes, hipMemcpyDeviceToDevice);
+    if (he != hipSuccess)
+    {
+        (void)hipFree(fresh.p);
+        return fail(RSR_E_DEVICE, std::string("blob copy: ") + hipGetErrorString(he));
+    }
+    if (blob.p) (void)hipFree(blob.p);
+    blob = fresh;
+    const PackedHeader* H = reinterpret_cast<const PackedHeader*>(head.data());
     const PackedConv* T = reinterpret_cast<const PackedConv*>(head.data() + sizeof(PackedHeader));
     convs.assign(T, T + H->nconv);
-    for (const PackedConv& c : convs)
-        if (c.w_off >= bytes || c.b_off >= bytes || c.nt == 0 || c.nt > 2 || c.nplanes == 0)
-            return fail(RSR_E_FORMAT, "packed blob conv table corrupt");
+    has_w32 = (H->flags & 1u) != 0;
     loaded = true;
     return RSR_OK;
 }
@@ -128,14 +187,13 @@ int Engine::load_files(const char* param, const char* bin)
 }
 
 // ---- plan ---------------------------------------------------------------------------------
-void Engine::free_plan()
+void Engine::free_plans()
 {
-    if (plan.d_tables)
-    {
-        (void)hipDeviceSynchronize();
-        (void)hipFree(plan.d_tables);
-    }
-    plan = Plan();
+    if (plans.empty()) return;
+    if (stream) (void)hipStreamSynchronize(stream); // kernels in flight read the tables
+    for (Plan& p : plans)
+        if (p.d_tables) (void)hipFree(p.d_tables);
+    plans.clear();
 }
 
 static void make_items(Plan::Batch& b)
@@ -163,16 +221,42 @@ static size_t batch_table_bytes(const Plan::Batch& b)
     return n;
 }
 
-// per-slot workspace bytes per LR pixel: IN 64, FEA 128, 3 x RDB 384, T32 256, R32 256, UP1 4*128,
-// UP2 16*128, HR 16*128, OUT3 16*6
-static constexpr long long kBytesPerPx = 64 + 128 + 3 * 384 + 256 + 256 + 512 + 2048 + 2048 + 96;
-
-int Engine::build_plan(int w, int h, int c)
+// upload one batch's tables behind `d`; every copy is checked
+static hipError_t upload_batch(Plan::Batch& b, char*& d)
 {
-    if (plan.w == w && plan.h == h && plan.c == c && plan.T == tilesize && plan.P == prepadding && plan.tta == tta &&
-        !plan.batches.empty())
-        return RSR_OK;
-    free_plan();
+    hipError_t err = hipSuccess;
+    auto put = [&](const void* src, size_t bytes) -> void* {
+        void* at = d;
+        if (bytes && err == hipSuccess) err = hipMemcpy(at, src, bytes, hipMemcpyHostToDevice);
+        d += al256(bytes);
+        return at;
+    };
+    b.d_tiles = static_cast<BaseTile*>(put(b.tiles.data(), b.tiles.size() * sizeof(BaseTile)));
+    b.d_dims = static_cast<TileDim*>(put(b.dims.data(), b.dims.size() * sizeof(TileDim)));
+    for (int l = 0; l < 3; l++)
+    {
+        b.d_items[l] = static_cast<WorkItem*>(put(b.items[l].data(), b.items[l].size() * sizeof(WorkItem)));
+        std::vector<WorkItem> rev(b.items[l].rbegin(), b.items[l].rend());
+        b.d_items_rev[l] = static_cast<WorkItem*>(put(rev.data(), rev.size() * sizeof(WorkItem)));
+    }
+    return err;
+}
+
+// per-slot workspace bytes per LR pixel: IN 64, FEA 128, 3 x RDB 384, T32 256, R32 256, UP1 4*128,
+// UP2 16*128, HR 16*128, OUT3 16*6   (the same for 16- and 32-channel planes)
+static constexpr long long kBytesPerPx = 64 + 128 + 3 * 384 + 256 + 256 + 512 + 2048 + 2048 + 96;
+static constexpr size_t kMaxPlans = 8;
+
+int Engine::get_plan(int w, int h, int c, Plan*& out)
+{
+    for (auto it = plans.begin(); it != plans.end(); ++it)
+        if (it->w == w && it->h == h && it->c == c && it->T == tilesize && it->P == prepadding && it->tta == tta &&
+            it->budget_mb == max_workspace_mb)
+        {
+            plans.splice(plans.begin(), plans, it); // most recently used first
+            out = &plans.front();
+            return RSR_OK;
+        }
     const int T = tilesize, P = prepadding;
     // tile grid: realsr.cpp:170-171; tile geometry: realsr.cpp:178-181,237,246-249
     const int xtiles = (w + T - 1) / T, ytiles = (h + T - 1) / T;
@@ -216,7 +300,9 @@ int Engine::build_plan(int w, int h, int c)
     const int spb = int(std::min<long long>(total_slots, budget_slots));
     const int tiles_per_batch = spb / per;
 
+    Plan plan;
     plan.w = w; plan.h = h; plan.c = c; plan.T = T; plan.P = P; plan.tta = tta;
+    plan.budget_mb = max_workspace_mb;
     plan.cap_px = cap;
     plan.max_tw = mtw;
     plan.max_th = mth;
@@ -240,64 +326,83 @@ int Engine::build_plan(int w, int h, int c)
         table_bytes += batch_table_bytes(b);
         plan.batches.push_back(std::move(b));
     }
+    if (plans.size() >= kMaxPlans)
+    { // evict the least recently used plan; kernels in flight may still read its tables
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (plans.back().d_tables) (void)hipFree(plans.back().d_tables);
+        plans.pop_back();
+    }
     HIP_TRY(hipMalloc(&plan.d_tables, table_bytes));
     char* d = static_cast<char*>(plan.d_tables);
     for (Plan::Batch& b : plan.batches)
     {
-        auto put = [&](const void* src, size_t bytes) -> void* {
-            void* at = d;
-            if (bytes) (void)hipMemcpy(at, src, bytes, hipMemcpyHostToDevice);
-            d += al256(bytes);
-            return at;
-        };
-        b.d_tiles = static_cast<BaseTile*>(put(b.tiles.data(), b.tiles.size() * sizeof(BaseTile)));
-        b.d_dims = static_cast<TileDim*>(put(b.dims.data(), b.dims.size() * sizeof(TileDim)));
-        for (int l = 0; l < 3; l++)
+        const hipError_t e = upload_batch(b, d);
+        if (e != hipSuccess)
         {
-            b.d_items[l] = static_cast<WorkItem*>(put(b.items[l].data(), b.items[l].size() * sizeof(WorkItem)));
-            std::vector<WorkItem> rev(b.items[l].rbegin(), b.items[l].rend());
-            b.d_items_rev[l] = static_cast<WorkItem*>(put(rev.data(), rev.size() * sizeof(WorkItem)));
+            (void)hipFree(plan.d_tables);
+            return fail(RSR_E_DEVICE, std::string("plan table upload: ") + hipGetErrorString(e));
         }
     }
-    HIP_TRY(hipGetLastError());
+    plans.push_front(std::move(plan));
+    out = &plans.front();
     return RSR_OK;
 }
 
 // Every fp16 plane that a convolution may read carries a 64-byte zero GUARD in front of pixel 0 (plane = [guard |
-// H*W*64 B]).  The LDS-DMA loaders address a plane as (uniform base, 32-bit lane offset); lanes whose patch pixel
-// lies outside the image use offset 0 = the guard, i.e. conv zero padding without a second base pointer.  Guards
-// are zeroed when a buffer is (re)allocated and never written afterwards.
-int Engine::ensure_zeroed(DevBuf& b, size_t bytes, bool layout_changed, hipStream_t st)
+// H*W*ppx B]).  The LDS-DMA loaders address a plane as (uniform base, 32-bit lane offset); lanes whose patch pixel
+// lies outside the image use offset 0 = the guard, i.e. conv zero padding without a second base pointer.
+// Invariant: every guard of the CURRENT layout inside the whole allocation is zero.  A fresh allocation is zeroed
+// completely; when the layout (plane stride) changes inside an existing allocation, the guards of the new layout are
+// zeroed over the WHOLE allocation (not just the slots this call uses: a later call with more slots of the same layout
+// must not find stale pixels where its guards are).  Guards are never written afterwards.
+int Engine::ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool layout_changed, bool zero_all, hipStream_t st)
 {
-    const void* before = b.p;
-    const size_t had = b.bytes;
-    const int rc = ensure(b, bytes);
-    if (rc != RSR_OK) return rc;
-    // a new plane stride moves the guards onto bytes that used to hold pixels: zero the used extent again
-    if (b.p != before || b.bytes != had || layout_changed) HIP_TRY(hipMemsetAsync(b.p, 0, bytes, st)); // same stream as the kernels that follow
+    const bool grow = !(b.bytes >= bytes && b.p);
+    if (grow)
+    {
+        const int rc = ensure(b, bytes);
+        if (rc != RSR_OK) return rc;
+        HIP_TRY(hipMemsetAsync(b.p, 0, b.bytes, st)); // same stream as the kernels that follow
+    }
+    else if (layout_changed)
+    {
+        if (zero_all) HIP_TRY(hipMemsetAsync(b.p, 0, b.bytes, st));
+        else launch_zero_guards(b.p, plane_bytes, (long long)(b.bytes / size_t(plane_bytes)), st);
+    }
     return RSR_OK;
 }
 
 int Engine::ensure_workspace(int nslots, long long cap, hipStream_t st)
 {
-    const size_t n = size_t(nslots), c = size_t(cap), G = size_t(kGuard);
-    const bool lc = (cap != ws_cap_px); // plane stride (hence guard positions) depends on the slot capacity
+    const int pc = plane_ch();
+    const size_t n = size_t(nslots), c = size_t(cap), G = size_t(kGuard), ppx = size_t(pc) * 2;
+    const size_t p32 = size_t(32 / pc), p64 = size_t(64 / pc);
+    const bool lc = (cap != ws_cap_px) || (pc != ws_plane_ch); // plane stride (hence guard positions) depends on both
+    const size_t need[] = {n * p32 * (c * ppx + G), n * p64 * (c * ppx + G), n * 3 * p64 * (c * ppx + G), n * p64 * (c * 4 * ppx + G),
+                           n * p64 * (c * 16 * ppx + G), n * c * 96, trunk_fp32 ? n * c * 256 : 0};
+    DevBuf* const bufs[] = {&b_in, &b_fea, &b_rdb[0], &b_up1, &b_up2, &b_out3, &b_t32};
+    bool any_grow = false;
+    for (int i = 0; i < 7; i++)
+        if (need[i] && !(bufs[i]->bytes >= need[i] && bufs[i]->p)) any_grow = true;
+    if (any_grow || lc) HIP_TRY(hipStreamSynchronize(st)); // nothing in flight may use a buffer that is freed / re-laid-out
     int rc;
-    if ((rc = ensure_zeroed(b_in, n * (c * 64 + G), lc, st)) != RSR_OK) return rc;
-    if ((rc = ensure_zeroed(b_fea, n * 2 * (c * 64 + G), lc, st)) != RSR_OK) return rc;
+    // b_in: with 16-channel planes its second plane (channels 16..31 of the padded 3-channel input) must stay zero
+    if ((rc = ensure_planes(b_in, need[0], long(c * ppx + G), lc, true, st)) != RSR_OK) return rc;
+    if ((rc = ensure_planes(b_fea, need[1], long(c * ppx + G), lc, false, st)) != RSR_OK) return rc;
     for (int i = 0; i < 3; i++)
-        if ((rc = ensure_zeroed(b_rdb[i], n * 6 * (c * 64 + G), lc, st)) != RSR_OK) return rc;
+        if ((rc = ensure_planes(b_rdb[i], need[2], long(c * ppx + G), lc, false, st)) != RSR_OK) return rc;
     if (trunk_fp32)
     {
         if ((rc = ensure(b_t32, n * c * 256)) != RSR_OK) return rc;
         if ((rc = ensure(b_r32, n * c * 256)) != RSR_OK) return rc;
     }
-    if ((rc = ensure_zeroed(b_up1, n * 2 * (c * 256 + G), lc, st)) != RSR_OK) return rc;
-    if ((rc = ensure_zeroed(b_up2, n * 2 * (c * 1024 + G), lc, st)) != RSR_OK) return rc;
-    if ((rc = ensure_zeroed(b_hr, n * 2 * (c * 1024 + G), lc, st)) != RSR_OK) return rc;
-    if ((rc = ensure(b_out3, n * c * 96)) != RSR_OK) return rc;
-    ws_slots = nslots;
+    if ((rc = ensure_planes(b_up1, need[3], long(c * 4 * ppx + G), lc, false, st)) != RSR_OK) return rc;
+    if ((rc = ensure_planes(b_up2, need[4], long(c * 16 * ppx + G), lc, false, st)) != RSR_OK) return rc;
+    if ((rc = ensure_planes(b_hr, need[4], long(c * 16 * ppx + G), lc, false, st)) != RSR_OK) return rc;
+    if ((rc = ensure(b_out3, need[5])) != RSR_OK) return rc;
+    HIP_TRY(hipGetLastError());
     ws_cap_px = cap;
+    ws_plane_ch = pc;
     return RSR_OK;
 }
 
@@ -359,15 +464,38 @@ void Engine::collect_profile(hipStream_t st)
 }
 
 // ---- the network schedule ---------------------------------------------------------------------
-// x4.param as a fused schedule.  Buffers (per slot, 32-channel planes):
-//   IN(1)  FEA(2)  RDB[3] x {x(2) + dense x1..x4 (4)}  T32/R32 (fp32 trunk / RRDB input, 2 planes each)
-//   UP1(2 @2x)  UP2(2 @4x)  HR(2 @4x)  OUT3 (planar [3][4H][4W] fp16)
+// x4.param as a fused schedule.  Buffers per slot, in planes of plane_ch() channels (P32 = planes
+// per 32 channels, P64 per 64):
+//   IN(P32; channels 3.. zero)  FEA(P64)  RDB[3] x {x(P64) + dense x1..x4 (4 x P32)}  T32/R32 (fp32 trunk, kernels 1-3)
+//   UP1(P64 @2x)  UP2(P64 @4x)  HR(P64 @4x)  OUT3 (planar [3][4H][4W] fp16)
 // Concat never happens: conv k of a dense block reads planes [x | x1..x_{k-1}] in place and writes its
-// 32 channels as plane x_k.  Eltwise/BinaryOp/Interp are epilogue or staging-address variants.
-void Engine::run_network(const Plan::Batch& b, hipStream_t st)
+// 32 channels as plane(s) x_k.  Eltwise/BinaryOp/Interp are epilogue or staging-address variants.
+int Engine::launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st)
+{
+    const PackedConv& c = convs[size_t(ci)];
+    const int kv = eff_kernel();
+    if (kv >= 4)
+    {
+        if (!launch_conv_flow(a, int(c.nt), num_cu, flow_flags, st))
+            return fail(RSR_E_STATE, "conv3x3_flow has no variant for convolution " + std::to_string(ci));
+    }
+    else
+    {
+        if (!has_w32) return fail(RSR_E_STATE, "this blob carries no 32-channel weight images (kernel 1-3 need rsr_model_pack's full blob)");
+        if (kv == 3 && c.nt == 1 && launch_conv_ring(a, int(c.nt), num_cu, st)) {}
+        else if (kv >= 2) launch_conv_pipe(a, int(c.nt), num_cu, st);
+        else launch_conv(a, int(c.nt), use_dma, st);
+    }
+    mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out], 0, st, ci);
+    return RSR_OK;
+}
+
+int Engine::run_network(const Plan::Batch& b, hipStream_t st)
 {
     const long long cap = ws_cap_px;
-    const long long pb16 = cap * 64 + kGuard, pb32 = cap * 128; // fp16 planes are guarded (see ensure_workspace)
+    const int pc = plane_ch(), P32 = 32 / pc, P64 = 64 / pc;
+    const long long ppx = pc * 2;
+    const long long pb16 = cap * ppx + kGuard, pb32 = cap * 128; // fp16 planes are guarded (see ensure_workspace)
     auto PS = [](const DevBuf& buf, long long planes_per_slot, long long plane_bytes, int plane_off) {
         PlaneSrc s; // base = pixel 0 of plane `plane_off` of slot 0
         s.base = static_cast<const char*>(buf.p) + (long long)plane_off * plane_bytes + kGuard;
@@ -382,15 +510,14 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         s.plane_stride = plane_bytes;
         return s;
     };
-    const PlaneSrc none{nullptr, 0, 0};
     const char* blobp = static_cast<const char*>(blob.p);
-    int ci = 0;
+    int ci = 0, rc = RSR_OK;
     auto base_args = [&](int lvl_in, int lvl_out) {
         ConvArgs a;
         std::memset(&a, 0, sizeof a);
         const PackedConv& c = convs[size_t(ci)];
-        a.wpk = blobp + c.w_off;
-        a.wfrag = blobp + c.wf_off;
+        a.wpk = has_w32 ? blobp + c.w_off : nullptr;
+        a.wpk16 = blobp + c.w16_off;
         a.bias = reinterpret_cast<const float*>(blobp + c.b_off);
         a.lrelu = (c.act == 2);
         a.lvl_in = lvl_in;
@@ -403,28 +530,23 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         a.dims = b.d_dims;
         a.zeros = zeros.p;
         a.dbg = dbg;
-        a.stagger = stagger_unit * int(c.nplanes + 2);
         a.trace = (trace_conv == ci) ? static_cast<unsigned long long*>(trace_buf.p) : nullptr;
         a.s1 = a.s2 = 1.f;
         return a;
     };
     auto go = [&](ConvArgs& a) {
-        const PackedConv& c = convs[size_t(ci)];
-        if (kernel_version == 3 && (c.nt == 1 || ring_nt2) && launch_conv_ring(a, int(c.nt), num_cu, st)) {}
-        else if (kernel_version >= 2) launch_conv_pipe(a, int(c.nt), num_cu, st);
-        else launch_conv(a, int(c.nt), use_dma, st);
-        mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out], 0, st, ci);
+        if (rc == RSR_OK) rc = launch(a, ci, b, st);
         ci++;
     };
-    const PlaneSrc fea = PS(b_fea, 2, pb16, 0);
+    const PlaneSrc fea = PS(b_fea, P64, pb16, 0);
     const PlaneSrc t32 = PS32(b_t32, 2, pb32, 0), r32 = PS32(b_r32, 2, pb32, 0);
-    auto rdb_x = [&](int i) { return PS(b_rdb[i], 6, pb16, 0); };
-    auto rdb_d = [&](int i, int k) { return PS(b_rdb[i], 6, pb16, 2 + k); };
+    auto rdb_x = [&](int i) { return PS(b_rdb[i], 3 * P64, pb16, 0); };
+    auto rdb_d = [&](int i, int k) { return PS(b_rdb[i], 3 * P64, pb16, P64 + k * P32); };
 
     { // conv_first (x4.param:4): IN -> FEA (+ fp32 trunk copies)
         ConvArgs a = base_args(0, 0);
-        a.src0 = PS(b_in, 1, pb16, 0);
-        a.n0 = 1;
+        a.src0 = PS(b_in, P32, pb16, 0);
+        a.n0 = P32;
         a.out16 = fea;
         if (trunk_fp32) { a.out32a = t32; a.out32b = r32; }
         go(a);
@@ -436,16 +558,16 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
         for (int k = 0; k < 4; k++)
         { // x_{k+1} = lrelu(conv([x, x1..xk]))   (x4.param:6,9,12,15)
             ConvArgs a = base_args(0, 0);
-            a.src0 = xs; a.n0 = 2;
-            a.src1 = rdb_d(bi, 0); a.n1 = k;
+            a.src0 = xs; a.n0 = P64;
+            a.src1 = rdb_d(bi, 0); a.n1 = k * P32;
             a.out16 = rdb_d(bi, k);
             go(a);
         }
         // x5 = conv([x, x1..x4]);  out = 0.2*x5 + x   (x4.param:17-18);  every third block additionally
         // out = 0.2*out + rrdb_in   (x4.param:47, Eltwise 0=1 -23301=2,0.2,1.0)
         ConvArgs a = base_args(0, 0);
-        a.src0 = xs; a.n0 = 2;
-        a.src1 = rdb_d(bi, 0); a.n1 = 4;
+        a.src0 = xs; a.n0 = P64;
+        a.src1 = rdb_d(bi, 0); a.n1 = 4 * P32;
         a.s1 = 0.2f;
         if (trunk_fp32) { a.res1 = t32; a.res1_kind = 2; a.out32a = t32; }
         else { a.res1 = xs; a.res1_kind = 1; a.res1_in_acc = !(dbg & 4096); a.res1_coef = 5.f; } // 1/0.2, exact in fp16
@@ -460,54 +582,55 @@ void Engine::run_network(const Plan::Batch& b, hipStream_t st)
     }
     { // trunk_conv + global skip: fea + conv(trunk)   (x4.param:994-995)
         ConvArgs a = base_args(0, 0);
-        a.src0 = rdb_x(kNumRDB % 3); a.n0 = 2;
+        a.src0 = rdb_x(kNumRDB % 3); a.n0 = P64;
         a.res1 = fea; a.res1_kind = 1; a.s1 = 1.f;
         a.out16 = rdb_x(1);
         go(a);
     }
-    const PlaneSrc up1 = PS(b_up1, 2, cap * 256 + kGuard, 0), up2 = PS(b_up2, 2, cap * 1024 + kGuard, 0), hr = PS(b_hr, 2, cap * 1024 + kGuard, 0);
+    const PlaneSrc up1 = PS(b_up1, P64, cap * 4 * ppx + kGuard, 0), up2 = PS(b_up2, P64, cap * 16 * ppx + kGuard, 0),
+                   hr = PS(b_hr, P64, cap * 16 * ppx + kGuard, 0);
     { // nearest x2 + upconv1 + lrelu   (x4.param:996-997)
         ConvArgs a = base_args(0, 1);
-        a.src0 = rdb_x(1); a.n0 = 2;
+        a.src0 = rdb_x(1); a.n0 = P64;
         a.out16 = up1;
         go(a);
     }
     { // nearest x2 + upconv2 + lrelu   (x4.param:998-999)
         ConvArgs a = base_args(1, 2);
-        a.src0 = up1; a.n0 = 2;
+        a.src0 = up1; a.n0 = P64;
         a.out16 = up2;
         go(a);
     }
     { // HRconv + lrelu   (x4.param:1000)
         ConvArgs a = base_args(2, 2);
-        a.src0 = up2; a.n0 = 2;
+        a.src0 = up2; a.n0 = P64;
         a.out16 = hr;
         go(a);
     }
     { // conv_last 64 -> 3   (x4.param:1001), planar fp16 output = the reference's `output` blob
         ConvArgs a = base_args(2, 2);
-        a.src0 = hr; a.n0 = 2;
+        a.src0 = hr; a.n0 = P64;
         a.out_planar3 = b_out3.p;
         a.planar3_slot_stride = cap * 96;
         go(a);
     }
-    (void)none;
+    return rc;
 }
 
 // ---- process ----------------------------------------------------------------------------------
-int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, bool sync)
+// enqueue preproc -> network -> postproc for every tile batch of one image on `st` (mu held)
+int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st)
 {
-    if (!loaded) return fail(RSR_E_STATE, "process before load");
-    if (!d_in || !d_out || w < 1 || h < 1 || (c != 3 && c != 4)) return fail(RSR_E_ARG, "bad image arguments");
-    if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
-    std::lock_guard<std::mutex> lk(mu);
-    HIP_TRY(hipSetDevice(device));
-    if (!st) st = stream;
-    int rc = build_plan(w, h, c);
+    Plan* planp = nullptr;
+    int rc = get_plan(w, h, c, planp);
     if (rc != RSR_OK) return rc;
+    const Plan& plan = *planp;
     rc = ensure_workspace(plan.slots_per_batch, plan.cap_px, st);
     if (rc != RSR_OK) return rc;
+    const int pc = plane_ch();
     mark_begin(st);
+    int done = 0, total = 0;
+    for (const Plan::Batch& b : plan.batches) total += b.ntiles;
     for (const Plan::Batch& b : plan.batches)
     {
         PreArgs pa;
@@ -517,11 +640,13 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
         pa.ntiles = b.ntiles;
         pa.tta = tta;
         pa.in_plane = static_cast<char*>(b_in.p) + kGuard;
-        pa.slot_stride = plan.cap_px * 64 + kGuard;
+        pa.slot_stride = (32 / pc) * (plan.cap_px * pc * 2 + kGuard);
         pa.bgr = 0;
+        pa.plane_ch = pc;
         launch_preproc_tiles(pa, plan.max_tw, plan.max_th, st);
         mark(0, 0, b.px[0] / (tta ? 8 : 1) * c + b.px[0] * 64, st);
-        run_network(b, st);
+        rc = run_network(b, st);
+        if (rc != RSR_OK) return rc;
         PostArgs po;
         po.planar3 = b_out3.p;
         po.slot_stride = plan.cap_px * 96;
@@ -537,6 +662,8 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
         po.bgr = 0;
         launch_postproc_tiles(po, (plan.max_tw - 2 * prepadding) * scale, (plan.max_th - 2 * prepadding) * scale, st);
         mark(2, 0, b.px[2] / (tta ? 8 : 1) * (6.0 * (tta ? 8 : 1) + c), st);
+        done += b.ntiles;
+        if (progress) progress(done, total, progress_user);
     }
     HIP_TRY(hipGetLastError());
     if (profiling)
@@ -545,73 +672,236 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
         prof.calls++;
         for (const Plan::Batch& b : plan.batches) prof.tiles += b.nslots;
     }
-    else if (sync) HIP_TRY(hipStreamSynchronize(st));
     return RSR_OK;
 }
 
+int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, hipStream_t user_stream, bool sync)
+{
+    if (!d_in || !d_out || w < 1 || h < 1 || (c != 3 && c != 4)) return fail(RSR_E_ARG, "bad image arguments");
+    hipEvent_t done = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!loaded) return fail(RSR_E_STATE, "process before load");
+        if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
+        HIP_TRY(hipSetDevice(device));
+        // All network kernels run on the engine's compute stream (one workspace); a caller stream is ordered around them.
+        if (user_stream)
+        {
+            hipEvent_t e = take_event();
+            if (!e) return fail(RSR_E_DEVICE, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e, user_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, e, 0));
+            give_event(e);
+        }
+        const int rc = enqueue_image(d_in, w, h, c, d_out, stream);
+        if (rc != RSR_OK) return rc;
+        if (user_stream || sync)
+        {
+            done = take_event();
+            if (!done) return fail(RSR_E_DEVICE, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(done, stream));
+            if (user_stream)
+            {
+                HIP_TRY(hipStreamWaitEvent(user_stream, done, 0));
+                give_event(done);
+                done = nullptr;
+            }
+        }
+    }
+    if (done)
+    { // wait outside the lock: other calls may enqueue behind this one meanwhile
+        const hipError_t e = hipEventSynchronize(done);
+        std::lock_guard<std::mutex> lk(mu);
+        give_event(done);
+        if (e != hipSuccess) return fail(RSR_E_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+    }
+    return RSR_OK;
+}
+
+Lane* Engine::acquire_lane()
+{
+    std::unique_lock<std::mutex> lk(lane_mu);
+    for (;;)
+    {
+        for (auto& l : lanes)
+            if (!l->busy)
+            {
+                l->busy = true;
+                return l.get();
+            }
+        if (int(lanes.size()) < max_lanes)
+        {
+            lanes.emplace_back(new Lane());
+            lanes.back()->busy = true;
+            return lanes.back().get();
+        }
+        lane_cv.wait(lk);
+    }
+}
+
+void Engine::release_lane(Lane* l)
+{
+    {
+        std::lock_guard<std::mutex> lk(lane_mu);
+        l->busy = false;
+    }
+    lane_cv.notify_one();
+}
+
+static bool is_pinned_host(const void* p)
+{
+    hipPointerAttribute_t at;
+    std::memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, p) != hipSuccess)
+    {
+        (void)hipGetLastError(); // plain malloc'd memory: "invalid value", not an error of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+static int ensure_pinned(void*& p, size_t& have, size_t need)
+{
+    if (have >= need && p) return RSR_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    have = 0;
+    const hipError_t e = hipHostMalloc(&p, need, hipHostMallocDefault);
+    if (e != hipSuccess)
+    {
+        p = nullptr;
+        (void)hipGetLastError();
+        return Engine::fail(RSR_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    have = need;
+    return RSR_OK;
+}
+
+// RealSR::process for host images.  The call owns a lane: upload on the lane's copy stream, kernels on the compute
+// stream (ordered by events), download on the copy stream again.  Pinned caller memory (rsr_host_alloc, hipHostMalloc,
+// hipHostRegister) is copied directly; pageable memory goes through the lane's pinned staging, the download in chunks so
+// that the CPU copy of chunk i overlaps the PCIe transfer of chunk i+1.
 int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out)
 {
     if (!in || !out || w < 1 || h < 1 || (c != 3 && c != 4)) return fail(RSR_E_ARG, "bad image arguments");
     const size_t nin = size_t(w) * h * c, nout = nin * size_t(scale) * scale;
+    Lane* L = acquire_lane();
+    struct Release
+    {
+        Engine* e;
+        Lane* l;
+        ~Release() { e->release_lane(l); }
+    } guard{this, L};
+    HIP_TRY(hipSetDevice(device));
+    if (!L->copy)
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&L->copy, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&L->ev_in, &L->ev_done, &L->ev_chunk[0], &L->ev_chunk[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    int rc;
+    if ((rc = ensure(L->d_in, nin)) != RSR_OK) return rc;  // lane-private: nothing else can be using the old allocation
+    if ((rc = ensure(L->d_out, nout)) != RSR_OK) return rc;
+
+    // ---- upload ----
+    const void* src = in;
+    if (!is_pinned_host(in))
+    {
+        if ((rc = ensure_pinned(L->h_in, L->h_in_bytes, nin)) != RSR_OK) return rc;
+        std::memcpy(L->h_in, in, nin);
+        src = L->h_in;
+    }
+    HIP_TRY(hipMemcpyAsync(L->d_in.p, src, nin, hipMemcpyHostToDevice, L->copy));
+    HIP_TRY(hipEventRecord(L->ev_in, L->copy));
+
+    // ---- network ----
     {
         std::lock_guard<std::mutex> lk(mu);
-        HIP_TRY(hipSetDevice(device));
-        int rc;
-        if ((rc = ensure(d_img_in, nin)) != RSR_OK) return rc;
-        if ((rc = ensure(d_img_out, nout)) != RSR_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(d_img_in.p, in, nin, hipMemcpyHostToDevice, stream));
+        if (!loaded) return fail(RSR_E_STATE, "process before load");
+        if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
+        HIP_TRY(hipStreamWaitEvent(stream, L->ev_in, 0));
+        rc = enqueue_image(L->d_in.p, w, h, c, L->d_out.p, stream);
+        if (rc != RSR_OK)
+        {
+            (void)hipStreamSynchronize(L->copy);
+            return rc;
+        }
+        HIP_TRY(hipEventRecord(L->ev_done, stream));
     }
-    int rc = process_device(d_img_in.p, w, h, c, d_img_out.p, stream, false);
-    if (rc != RSR_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(out, d_img_out.p, nout, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_done, 0));
+
+    // ---- download ----
+    if (is_pinned_host(out))
+    {
+        HIP_TRY(hipMemcpyAsync(out, L->d_out.p, nout, hipMemcpyDeviceToHost, L->copy));
+        HIP_TRY(hipStreamSynchronize(L->copy));
+        return RSR_OK;
+    }
+    const size_t CH = std::max<size_t>(chunk_bytes, 1 << 20);
+    if ((rc = ensure_pinned(L->h_out, L->h_out_bytes, 2 * std::min(CH, nout))) != RSR_OK) return rc;
+    const size_t half = L->h_out_bytes / 2;
+    const size_t nchunks = (nout + half - 1) / half;
+    const char* dsrc = static_cast<const char*>(L->d_out.p);
+    for (size_t i = 0; i <= nchunks; i++)
+    {
+        if (i < nchunks)
+        {
+            const size_t off = i * half, n = std::min(half, nout - off);
+            // slot i&1 was drained by the CPU copy of chunk i-2 in the previous iteration
+            HIP_TRY(hipMemcpyAsync(static_cast<char*>(L->h_out) + (i & 1) * half, dsrc + off, n, hipMemcpyDeviceToHost, L->copy));
+            HIP_TRY(hipEventRecord(L->ev_chunk[i & 1], L->copy));
+        }
+        if (i >= 1)
+        {
+            const size_t k = i - 1, off = k * half, n = std::min(half, nout - off);
+            HIP_TRY(hipEventSynchronize(L->ev_chunk[k & 1]));
+            std::memcpy(out + off, static_cast<const char*>(L->h_out) + (k & 1) * half, n);
+        }
+    }
     return RSR_OK;
 }
 
 // one tile through the network only (layer-level parity hook)
 int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out)
 {
-    if (!loaded) return fail(RSR_E_STATE, "net_forward before load");
     if (!in || !out || w < 1 || h < 1) return fail(RSR_E_ARG, "bad arguments");
     std::lock_guard<std::mutex> lk(mu);
+    if (!loaded) return fail(RSR_E_STATE, "net_forward before load");
     HIP_TRY(hipSetDevice(device));
-    free_plan();
+    HIP_TRY(hipStreamSynchronize(stream));
     Plan::Batch b;
     b.ntiles = 1;
     b.nslots = 1;
     b.dims.push_back(TileDim{h, w});
     make_items(b);
-    plan.cap_px = (long long)w * h;
-    plan.batches.clear();
-    size_t tb = batch_table_bytes(b);
-    HIP_TRY(hipMalloc(&plan.d_tables, tb));
-    char* d = static_cast<char*>(plan.d_tables);
-    b.d_dims = reinterpret_cast<TileDim*>(d);
-    HIP_TRY(hipMemcpy(d, b.dims.data(), sizeof(TileDim), hipMemcpyHostToDevice));
-    d += 256;
-    for (int l = 0; l < 3; l++)
-    {
-        b.d_items[l] = reinterpret_cast<WorkItem*>(d);
-        HIP_TRY(hipMemcpy(d, b.items[l].data(), b.items[l].size() * sizeof(WorkItem), hipMemcpyHostToDevice));
-        d += al256(b.items[l].size() * sizeof(WorkItem));
-    }
-    int rc = ensure_workspace(1, plan.cap_px, stream);
-    if (rc != RSR_OK) return rc;
+    const long long cap = (long long)w * h;
+    if (cap * 16 * 64 >= (1ll << 31)) return fail(RSR_E_ARG, "tile too large");
+    DevBuf tab, tmp;
+    auto cleanup = [&]() {
+        if (tab.p) (void)hipFree(tab.p);
+        if (tmp.p) (void)hipFree(tmp.p);
+    };
+    int rc;
+    if ((rc = ensure(tab, batch_table_bytes(b))) != RSR_OK) return rc;
+    char* d = static_cast<char*>(tab.p);
+    hipError_t he = upload_batch(b, d);
     const size_t npx = size_t(w) * h;
-    DevBuf tmp;
-    if ((rc = ensure(tmp, npx * 6)) != RSR_OK) return rc;
-    HIP_TRY(hipMemcpy(tmp.p, in, npx * 6, hipMemcpyHostToDevice));
-    launch_planar3_to_plane(static_cast<const uint16_t*>(tmp.p), w, h, static_cast<char*>(b_in.p) + kGuard, stream);
-    const bool was = profiling;
-    profiling = false;
-    run_network(b, stream);
-    profiling = was;
-    HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, b_out3.p, npx * 16 * 6, hipMemcpyDeviceToHost));
-    (void)hipFree(tmp.p);
-    free_plan();
-    return RSR_OK;
+    if (he == hipSuccess && (rc = ensure_workspace(1, cap, stream)) != RSR_OK) { cleanup(); return rc; }
+    if (he == hipSuccess && (rc = ensure(tmp, npx * 6)) != RSR_OK) { cleanup(); return rc; }
+    if (he == hipSuccess) he = hipMemcpy(tmp.p, in, npx * 6, hipMemcpyHostToDevice);
+    if (he == hipSuccess)
+    {
+        launch_planar3_to_plane(static_cast<const uint16_t*>(tmp.p), w, h, static_cast<char*>(b_in.p) + kGuard, plane_ch(), stream);
+        const bool was = profiling;
+        profiling = false;
+        rc = run_network(b, stream);
+        profiling = was;
+        he = hipStreamSynchronize(stream);
+        if (he == hipSuccess) he = hipGetLastError();
+        if (he == hipSuccess && rc == RSR_OK) he = hipMemcpy(out, b_out3.p, npx * 16 * 6, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (he != hipSuccess) return fail(RSR_E_DEVICE, std::string("net_forward: ") + hipGetErrorString(he));
+    return rc;
 }
 
 // one convolution with caller-supplied weights (layer-level parity hook, include/realsr_hip.h rsr_conv3x3)
@@ -632,14 +922,17 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     int rc = pack_model(m, pk.data(), pk.size(), e);
     if (rc != RSR_OK) return fail(rc, e);
     const PackedConv pc = *reinterpret_cast<const PackedConv*>(pk.data() + sizeof(PackedHeader));
-    const int np = int(pc.nplanes), nt = int(pc.nt);
+    const int kv = (kernel_version >= 4) ? 4 : kernel_version; // the layer hook has no fp32 trunk
+    const int pch = kv >= 4 ? 16 : 32;
+    const int np = int(pc.nplanes) * (32 / pch), nt = int(pc.nt); // input planes (cin padded to a multiple of 32)
+    const int npo = nt * (32 / pch);                              // output planes
     const int H = ups ? 2 * h : h, W = ups ? 2 * w : w;
     const size_t ipx = size_t(h) * w, opx = size_t(H) * W;
-    // planar [cin][h][w] -> planes [np][h][w][32]
-    const size_t ipl = ipx * 32 + kGuard / 2; // halfs per guarded input plane
-    std::vector<uint16_t> hin(size_t(np) * ipl, 0), hout(size_t(nt) * opx * 32, 0);
+    // planar [cin][h][w] -> guarded planes [np][h][w][pch]
+    const size_t ipl = ipx * size_t(pch) + kGuard / 2; // halfs per guarded input plane
+    std::vector<uint16_t> hin(size_t(np) * ipl, 0), hout(size_t(npo) * opx * size_t(pch), 0);
     for (int ch = 0; ch < cin; ch++)
-        for (size_t p = 0; p < ipx; p++) hin[size_t(ch / 32) * ipl + kGuard / 2 + p * 32 + size_t(ch % 32)] = in[size_t(ch) * ipx + p];
+        for (size_t p = 0; p < ipx; p++) hin[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = in[size_t(ch) * ipx + p];
     DevBuf d_w, d_in, d_out, d_tab;
     std::vector<WorkItem> items;
     for (int y0 = 0; y0 < H; y0 += kBlkH)
@@ -655,37 +948,46 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         cleanup();
         return rc;
     }
-    (void)hipMemcpy(d_w.p, pk.data(), pk.size(), hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_in.p, hin.data(), hin.size() * 2, hipMemcpyHostToDevice);
-    (void)hipMemsetAsync(d_out.p, 0, hout.size() * 2, stream);
-    (void)hipMemcpy(d_tab.p, &td, sizeof td, hipMemcpyHostToDevice);
-    (void)hipMemcpy(static_cast<char*>(d_tab.p) + 256, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice);
-    ConvArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.src0 = PlaneSrc{static_cast<char*>(d_in.p) + kGuard, 0, (long long)ipx * 64 + kGuard};
-    a.n0 = np;
-    a.lvl_in = 0;
-    a.lvl_out = ups ? 1 : 0;
-    a.wpk = static_cast<const char*>(d_w.p) + pc.w_off;
-    a.wfrag = static_cast<const char*>(d_w.p) + pc.wf_off;
-    a.bias = reinterpret_cast<const float*>(static_cast<const char*>(d_w.p) + pc.b_off);
-    a.lrelu = lrelu;
-    a.s1 = a.s2 = 1.f;
-    a.out16 = PlaneSrc{d_out.p, 0, (long long)opx * 64};
-    a.items = reinterpret_cast<const WorkItem*>(static_cast<const char*>(d_tab.p) + 256);
-    a.nitems = int(items.size());
-    a.dims = static_cast<const TileDim*>(d_tab.p);
-    a.zeros = zeros.p;
-    if (kernel_version == 3 && (nt == 1 || ring_nt2) && launch_conv_ring(a, nt, num_cu, stream)) {}
-    else if (kernel_version >= 2) launch_conv_pipe(a, nt, num_cu, stream);
-    else launch_conv(a, nt, use_dma, stream);
-    hipError_t he = hipStreamSynchronize(stream);
-    if (he == hipSuccess) he = hipGetLastError();
-    if (he == hipSuccess) he = hipMemcpy(hout.data(), d_out.p, hout.size() * 2, hipMemcpyDeviceToHost);
+    hipError_t he = hipMemcpy(d_w.p, pk.data(), pk.size(), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(d_in.p, hin.data(), hin.size() * 2, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemsetAsync(d_out.p, 0, hout.size() * 2, stream);
+    if (he == hipSuccess) he = hipMemcpy(d_tab.p, &td, sizeof td, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(static_cast<char*>(d_tab.p) + 256, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice);
+    if (he == hipSuccess)
+    {
+        ConvArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.src0 = PlaneSrc{static_cast<char*>(d_in.p) + kGuard, 0, (long long)ipx * pch * 2 + kGuard};
+        a.n0 = np;
+        a.lvl_in = 0;
+        a.lvl_out = ups ? 1 : 0;
+        a.wpk = static_cast<const char*>(d_w.p) + pc.w_off;
+        a.wpk16 = static_cast<const char*>(d_w.p) + pc.w16_off;
+        a.bias = reinterpret_cast<const float*>(static_cast<const char*>(d_w.p) + pc.b_off);
+        a.lrelu = lrelu;
+        a.s1 = a.s2 = 1.f;
+        a.out16 = PlaneSrc{d_out.p, 0, (long long)opx * pch * 2};
+        a.items = reinterpret_cast<const WorkItem*>(static_cast<const char*>(d_tab.p) + 256);
+        a.nitems = int(items.size());
+        a.dims = static_cast<const TileDim*>(d_tab.p);
+        a.zeros = zeros.p;
+        a.dbg = dbg;
+        if (kv >= 4)
+        {
+            if (!launch_conv_flow(a, nt, num_cu, flow_flags, stream)) rc = fail(RSR_E_STATE, "conv3x3_flow: no variant");
+        }
+        else if (kv == 3 && nt == 1 && launch_conv_ring(a, nt, num_cu, stream)) {}
+        else if (kv >= 2) launch_conv_pipe(a, nt, num_cu, stream);
+        else launch_conv(a, nt, use_dma, stream);
+        he = hipStreamSynchronize(stream);
+        if (he == hipSuccess) he = hipGetLastError();
+        if (he == hipSuccess) he = hipMemcpy(hout.data(), d_out.p, hout.size() * 2, hipMemcpyDeviceToHost);
+    }
     cleanup();
     if (he != hipSuccess) return fail(RSR_E_DEVICE, std::string("conv_test: ") + hipGetErrorString(he));
+    if (rc != RSR_OK) return rc;
     for (int ch = 0; ch < cout; ch++)
-        for (size_t p = 0; p < opx; p++) out[size_t(ch) * opx + p] = hout[(size_t(ch / 32) * opx + p) * 32 + size_t(ch % 32)];
+        for (size_t p = 0; p < opx; p++) out[size_t(ch) * opx + p] = hout[(size_t(ch / pch) * opx + p) * size_t(pch) + size_t(ch % pch)];
     return RSR_OK;
 }
 

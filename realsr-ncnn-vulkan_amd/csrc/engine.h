@@ -4,9 +4,20 @@
 // one Vulkan submit_and_wait per tile and >= 722 dispatches per tile, ALL tiles of an image (x8 under
 // TTA) are laid out as "slots" of one batch and walk the 351 convolutions together: one kernel launch
 // per network layer per batch, no host synchronisation inside a call.
+//
+// Concurrency (the reference calls RealSR::process from several proc threads on one object, main.cpp:811-828,
+// with per-call allocators, realsr.cpp:161-167):
+//   * every rsr_process call owns a LANE for its duration: private device image buffers, private pinned staging,
+//     a private copy stream and events -- nothing of a call's data path is shared with another call;
+//   * the network itself runs on ONE compute stream over ONE workspace; calls enqueue their kernels under `mu`
+//     (a few hundred microseconds of host time) and the GPU executes them in that order.  A lane's upload runs
+//     ahead of, and its download behind, the other lanes' kernels: H2D(k+1) | kernels(k) | D2H(k-1) overlap.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
+#include <list>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,10 +34,11 @@ struct DevBuf
     size_t bytes = 0;
 };
 
-// geometry of one rsr_process call; cached between calls with identical (w,h,c,T,P,tta)
+// geometry of one rsr_process call; cached per (w,h,c,T,P,tta,budget)
 struct Plan
 {
     int w = 0, h = 0, c = 0, T = 0, P = 0, tta = 0;
+    long long budget_mb = 0;
     long long cap_px = 0; // slot capacity in LR pixels
     int max_tw = 0, max_th = 0;
     struct Batch
@@ -47,41 +59,61 @@ struct Plan
     void* d_tables = nullptr; // one allocation backing all device tables
 };
 
+// one in-flight rsr_process call (host API)
+struct Lane
+{
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_chunk[2] = {nullptr, nullptr};
+    DevBuf d_in, d_out;
+    void* h_in = nullptr;
+    size_t h_in_bytes = 0;
+    void* h_out = nullptr; // two download chunks
+    size_t h_out_bytes = 0;
+    bool busy = false;
+};
+
 struct Engine
 {
     int device = -1;
     int tta = 0;
     int scale = 4, tilesize = 200, prepadding = 10;
     bool loaded = false;
-    bool trunk_fp32 = false; // residual trunk storage: fp16 like the reference Vulkan path (realsr.cpp:45); true = extra fp32 copy
+    bool trunk_fp32 = false; // residual trunk storage: fp16 like the reference Vulkan path (realsr.cpp:45); true = extra fp32 copy (kernels 1-3)
     bool use_dma = true;
-    int kernel_version = 3; // 3: conv3x3_ring, 2: conv3x3_pipe, 1: conv3x3_mfma
+    // 4: conv3x3_flow on 16-channel planes (default); 3: conv3x3_ring + conv3x3_pipe, 2: conv3x3_pipe, 1: conv3x3_mfma (32-channel planes)
+    int kernel_version = 4;
+    int flow_flags = 0; // launch_conv_flow flags
     int num_cu = 256;
-    bool ring_nt2 = false; // use conv3x3_ring also for 64-output-channel convs (slower there: 168-VGPR budget)
     int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
-    int stagger_unit = 0; // s_sleep units (64 cycles) per (chunk + 2) of start delay between workgroup phases
     bool alternate_order = true; // odd convs walk the work items backwards: they start on the data the previous conv touched last
     int trace_conv = -1; // conv index whose launch records s_memtime stamps into trace_buf (profiling only)
     DevBuf trace_buf;
     long long max_workspace_mb = 65536;
-    hipStream_t stream = nullptr;
+    int max_lanes = 4;
+    size_t chunk_bytes = size_t(16) << 20; // download chunk for pageable destinations
+    hipStream_t stream = nullptr;          // the compute stream
 
     // model
     std::vector<PackedConv> convs;
+    bool has_w32 = false;
     DevBuf blob; // packed weights on device
     DevBuf zeros;
 
-    // workspace (one allocation per buffer kind, nslots each)
-    int ws_slots = 0;
+    // workspace (one allocation per buffer kind), layout = (plane channels, slot capacity)
+    int ws_plane_ch = 0;
     long long ws_cap_px = 0;
     DevBuf b_in, b_fea, b_rdb[3], b_t32, b_r32, b_up1, b_up2, b_hr, b_out3;
 
-    // image staging for the host API
-    DevBuf d_img_in, d_img_out;
+    // plans, most recently used first
+    std::list<Plan> plans;
 
-    Plan plan;
-    std::mutex mu;
-    std::string err;
+    // lanes
+    std::mutex lane_mu;
+    std::condition_variable lane_cv;
+    std::vector<std::unique_ptr<Lane>> lanes;
+
+    std::mutex mu; // compute section: plan cache, workspace, kernel enqueue, profiling state
+    std::vector<hipEvent_t> sync_events; // free list, under mu
 
     // profiling
     bool profiling = false;
@@ -96,28 +128,44 @@ struct Engine
     std::vector<Seg> segs;
     size_t ev_used = 0;
     rsr_profile prof{};
+    void (*progress)(int done, int total, void* user) = nullptr; // per tile batch (the reference prints per tile, realsr.cpp:481)
+    void* progress_user = nullptr;
 
     ~Engine();
     int init(int gpuid, int tta_mode);
     int load_files(const char* param, const char* bin);
     int load_blob_host(const void* blob, size_t bytes);
     int load_blob_device(const void* blob, size_t bytes);
-    int process_device(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, bool sync);
+    // d_in/d_out on this device.  user_stream == nullptr: returns when the output is complete (sync) or enqueued (!sync);
+    // otherwise ordered after / before the work of user_stream, asynchronous.
+    int process_device(const void* d_in, int w, int h, int c, void* d_out, hipStream_t user_stream, bool sync);
     int process_host(const uint8_t* in, int w, int h, int c, uint8_t* out);
     int net_forward(const uint16_t* in, int w, int h, uint16_t* out);
     int conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout, int lrelu,
                   uint16_t* out);
 
+    // ---- internals (call with `mu` held unless noted) ----
+    int plane_ch() const { return (kernel_version >= 4 && !trunk_fp32) ? 16 : 32; }
+    int eff_kernel() const { return (kernel_version >= 4 && trunk_fp32) ? 3 : kernel_version; }
     int ensure(DevBuf& b, size_t bytes);
-    int ensure_zeroed(DevBuf& b, size_t bytes, bool layout_changed, hipStream_t st);
-    int build_plan(int w, int h, int c);
+    int ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool layout_changed, bool zero_all, hipStream_t st);
+    int get_plan(int w, int h, int c, Plan*& out);
     int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
-    void run_network(const Plan::Batch& b, hipStream_t st);
+    int run_network(const Plan::Batch& b, hipStream_t st);
+    int launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st);
+    int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st);
     void mark_begin(hipStream_t st);
     void mark(int cls, double flops, double bytes, hipStream_t st, int conv_index = -1);
     void collect_profile(hipStream_t st);
-    void free_plan();
-    int fail(int code, const std::string& msg);
+    void free_plans();
+    hipEvent_t take_event();
+    void give_event(hipEvent_t e);
+    Lane* acquire_lane(); // lane_mu inside
+    void release_lane(Lane* l);
+    int adopt_table(const unsigned char* head, size_t bytes); // validated header -> convs
+    static int fail(int code, const std::string& msg);
 };
+
+const char* last_error(); // message of the calling thread's last failure
 
 } // namespace rsr

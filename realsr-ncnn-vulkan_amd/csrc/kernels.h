@@ -50,8 +50,8 @@ struct ConvArgs
     int lvl_in;  // input resolution = LR << lvl_in
     int lvl_out; // output resolution = LR << lvl_out (lvl_out == lvl_in + 1 for the nearest-x2 fused convs)
     // weights: packed LDS images, one per 32-cin chunk; bias fp32 [NT*32]
-    const void* wpk;
-    const void* wfrag; // fragment-major weights (model.h PackedConv::wf_off), read directly by conv3x3_ring's MFMA waves
+    const void* wpk;   // kernels 1-3 (32-channel planes): LDS images [chunk of 32 cin][9 taps][NT*32 cout][32 cin]
+    const void* wpk16; // conv3x3_flow (16-channel planes): LDS images [plane of 16 cin][9 taps][NT*32 cout][16 cin]
     const float* bias;
     int lrelu; // LeakyReLU(0.2) on (acc + bias)
     // residual stages: v = v*s + r  (r fp32 plane or fp16 plane)
@@ -73,14 +73,18 @@ struct ConvArgs
     const TileDim* dims;
     const void* zeros; // >= 16 zero bytes in device memory (LDS-DMA source for out-of-image pixels)
     unsigned long long* trace; // optional: block 0 / wave 0 writes per-stage s_memtime stamps (profiling aid), 2 x u64 per stage
-    int stagger;       // conv3x3_ring: workgroup j delays its start by (j & 3) * stagger * 64 cycles so that the epilogue (store)
-                       // bursts of the 256 lock-stepped workgroups do not all hit HBM at the same moment
-    int dbg;           // ablation switches for profiling (conv3x3_pipe): 1 skip DMA, 2 skip MFMA, 4 skip epilogue, 8 coalesced epilogue
+    int dbg;           // ablation switches for profiling: 1 skip DMA, 2 skip MFMA, 4 skip epilogue stores, ...  (realsr_hip.h)
 };
 
 void launch_conv(const ConvArgs& a, int nt, bool dma, hipStream_t st);
 void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st); // persistent wave-specialised variant
-bool launch_conv_ring(const ConvArgs& a, int nt, int ncu, hipStream_t st); // + 3-stage patch ring, weights from L2; false = does not fit
+bool launch_conv_ring(const ConvArgs& a, int nt, int ncu, hipStream_t st); // + 3-stage patch ring; false = does not fit (64 output channels)
+// conv_flow.hip: half-stage ring on 16-channel planes.  flags: 1 = two n-tiles per MFMA wave for 64-cout convs, 2 = no deferred epilogue.
+// false = this combination of outputs / residuals is not covered (the engine then reports an error)
+bool launch_conv_flow(const ConvArgs& a, int nt, int ncu, int flags, hipStream_t st);
+// Opt-in to > 64 KiB of dynamic LDS for every kernel instantiation, on the CURRENT device (call once per device).
+hipError_t kernels_init_device();
+hipError_t flow_init_device();
 
 // ---- pre / post ------------------------------------------------------------------------------
 struct BaseTile
@@ -99,9 +103,10 @@ struct PreArgs
     const BaseTile* tiles;
     int ntiles;
     int tta;
-    void* in_plane; // fp16 plane [th][tw][32] per slot, channels 0..2 = RGB/255, rest 0
+    void* in_plane; // fp16 plane [th][tw][plane_ch] per slot, channels 0..2 = RGB/255, rest 0
     long long slot_stride;
     int bgr;
+    int plane_ch;   // 32 (round-1 kernels) or 16 (conv3x3_flow)
 };
 void launch_preproc_tiles(const PreArgs& a, int max_tw, int max_th, hipStream_t st);
 
@@ -130,7 +135,9 @@ void launch_postproc_shader(const uint16_t* const bottom[8], int nbottom, int w,
                             int alphaw, int alphah, uint8_t* top, int outw, int outh, int offset_x, int gx_max, int crop_x,
                             int crop_y, int channels, int bgr, hipStream_t st);
 
-// planar fp16 [3][h][w]  <->  plane [h][w][32] (net_forward test hook)
-void launch_planar3_to_plane(const uint16_t* planar, int w, int h, void* plane, hipStream_t st);
+// planar fp16 [3][h][w]  ->  plane [h][w][plane_ch] (net_forward test hook)
+void launch_planar3_to_plane(const uint16_t* planar, int w, int h, void* plane, int plane_ch, hipStream_t st);
+// zero the 64-byte guards of `count` planes, `stride` bytes apart
+void launch_zero_guards(void* first_guard, long long stride, long long count, hipStream_t st);
 
 } // namespace rsr

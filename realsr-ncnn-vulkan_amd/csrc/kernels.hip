@@ -519,76 +519,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma(const ConvArgs a)
     }
 
     // ---- epilogue ----
-    const int x = x0 + l32;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
     {
         f32x4 bq[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(a.bias + nt * 32 + q * 8 + hi * 4);
+        f32x16 accn[4];
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-        {
-            const int y = y0 + wave * 4 + rr;
-            if (y >= H || x >= W) continue;
-            const long long pix = (long long)y * W + x;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-            {
-                const int c0 = q * 8 + hi * 4; // channel within the 32-plane
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                {
-                    float t = acc[rr][nt][q * 4 + e] + bq[q][e];
-                    if (a.lrelu) t = t > 0.f ? t : t * 0.2f;
-                    v[e] = t;
-                }
-                if (a.res1_kind == 2)
-                {
-                    const f32x4 r = *reinterpret_cast<const f32x4*>(plane_ptr(a.res1, slot, nt) + (pix * 32 + c0) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s1 + r[e];
-                }
-                else if (a.res1_kind == 1)
-                {
-                    const half4 r = *reinterpret_cast<const half4*>(plane_ptr(a.res1, slot, nt) + (pix * 32 + c0) * 2);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s1 + (float)r[e];
-                }
-                if (a.res2_kind == 2)
-                {
-                    const f32x4 r = *reinterpret_cast<const f32x4*>(plane_ptr(a.res2, slot, nt) + (pix * 32 + c0) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s2 + r[e];
-                }
-                else if (a.res2_kind == 1)
-                {
-                    const half4 r = *reinterpret_cast<const half4*>(plane_ptr(a.res2, slot, nt) + (pix * 32 + c0) * 2);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = v[e] * a.s2 + (float)r[e];
-                }
-                if (a.out16.base)
-                {
-                    half4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) o[e] = (_Float16)v[e];
-                    *reinterpret_cast<half4*>(const_cast<char*>(plane_ptr(a.out16, slot, nt)) + (pix * 32 + c0) * 2) = o;
-                }
-                if (a.out32a.base)
-                    *reinterpret_cast<f32x4*>(const_cast<char*>(plane_ptr(a.out32a, slot, nt)) + (pix * 32 + c0) * 4) = v;
-                if (a.out32b.base)
-                    *reinterpret_cast<f32x4*>(const_cast<char*>(plane_ptr(a.out32b, slot, nt)) + (pix * 32 + c0) * 4) = v;
-                if (a.out_planar3 && nt == 0 && q == 0 && hi == 0)
-                {
-                    _Float16* o = reinterpret_cast<_Float16*>(static_cast<char*>(a.out_planar3) + (long long)slot * a.planar3_slot_stride);
-                    const long long hw = (long long)H * W;
-                    o[pix] = (_Float16)v[0];
-                    o[hw + pix] = (_Float16)v[1];
-                    o[2 * hw + pix] = (_Float16)v[2];
-                }
-            }
-        }
+        for (int rr = 0; rr < 4; rr++) accn[rr] = acc[rr][nt];
+        conv_epilogue(a, accn, bq, nt, slot, y0, x0, H, W, wave, l32, hi);
     }
 }
 
@@ -613,13 +553,6 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
     constexpr int WITEMS = WROWS * 4;
     constexpr int WPASS = (WITEMS + 255) / 256;
     constexpr int STAGE = kPatchLds + WROWS * 64;
-    // EPI 3 ("outbox", NT == 1, act-only epilogue, >= 2 chunks per item): the compute waves only drop their finished
-    // block as fp16 into a 32-KiB LDS outbox (16 ds_write_b64 per wave) and go straight on to the next item; the
-    // LOADER waves -- idle between two DMA bursts -- drain it one barrier later with 16-B loads and fully coalesced
-    // 1-KiB global stores.  The store path (and its texture-addresser time) leaves the MFMA waves' critical path.
-    constexpr bool OUTBOX = (EPI == 3);
-    static_assert(!OUTBOX || NT == 1, "outbox epilogue is built for NT == 1");
-    constexpr int OUTBOX_OFF = 2 * STAGE + 256 + 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -642,28 +575,11 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 const char* wbase = static_cast<const char*>(a.wpk);
         int t = 0;
         WorkItem nxt = a.items[first];
-        WorkItem prev = nxt;
-        // outbox drain (loader side): lane -> (column, 16-B piece) fixed, 8 passes walk the 16 rows two at a time
-        const int dcol = (ltid >> 2) & 31, dpiece = ltid & 3, drow0 = ltid >> 7;
-        const int dlds = OUTBOX_OFF + (drow0 * 32 + dcol) * 64 + ((dpiece ^ ((dcol >> 1) & 3)) << 4);
-        auto drain = [&](const WorkItem& pi) {
-            char* outp = const_cast<char*>(plane_ptr(a.out16, pi.slot, 0));
-            const int x = pi.x0 + dcol;
-#pragma unroll
-            for (int pass = 0; pass < 8; pass++)
-            {
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + dlds + pass * (2 * 32 * 64));
-                const int y = pi.y0 + pass * 2 + drow0;
-                if (y < pi.H && x < pi.W) *reinterpret_cast<uint4*>(outp + ((long long)y * pi.W + x) * 64 + dpiece * 16) = v;
-            }
-        };
         for (int r = 0; r < nmine; r++)
         {
             // the descriptor of item r was fetched one item ago; item r+1's is requested now and lands while
             // this item's stages stream (no dependent global load sits in front of a DMA issue)
-            const WorkItem before = prev;
             const WorkItem it = nxt;
-            prev = it;
             if (r + 1 < nmine) nxt = a.items[first + (r + 1) * nj];
             const int H = it.H, W = it.W, Wi = UPS ? (W >> 1) : W;
             // byte offset of every patch item of this lane from (plane pixel 0 - kGuard); 0 = the plane's zero guard
@@ -689,9 +605,6 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                     // that buffer t&1 is free.
                     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 }
-                // the barrier just passed at (r >= 1, ck == 1) is the one the compute waves reached after writing the
-                // previous item's outbox; they will not write it again before the NEXT barrier (>= 2 chunks per item)
-                if (OUTBOX && r > 0 && ck == 1) drain(before);
                 char* buf = smem + (t & 1) * STAGE + lw * 1024;
                 const char* gbase = ((ck < a.n0) ? plane_ptr(a.src0, it.slot, ck) : plane_ptr(a.src1, it.slot, ck - a.n0)) - kGuard;
                 const char* wsrc = wbase + (long long)ck * (WROWS * 64) + (lw * 64 + lane) * 16;
@@ -715,11 +628,6 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
             }
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // barrier B_{S-1}
-        if (OUTBOX)
-        {
-            asm volatile("s_barrier" ::: "memory"); // B_S: the last item's outbox is complete
-            drain(prev);
-        }
         return;
     }
 
@@ -768,7 +676,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
         unsigned long long t_arrive = 0;
         const bool tracing = a.trace && blockIdx.x == 0 && wave == 0;
         if (tracing) t_arrive = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // barrier B_s: stage s is in LDS (our outbox writes landed)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // barrier B_s: stage s is in LDS
         if (tracing && s < 512 && lane == 0)
         {
             a.trace[2 * s] = t_arrive;
@@ -854,28 +762,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 f32x4 bq[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(bias_lds + ntw * 32 + q * 8 + hi * 4);
-                if (OUTBOX)
-                {
-                    const float slope = a.lrelu ? 0.2f : 1.f;
-                    char* ob = smem + OUTBOX_OFF + l32 * 64 + hi * 8;
-                    const int swz = (l32 >> 1) & 3;
-#pragma unroll
-                    for (int rr = 0; rr < 4; rr++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++)
-                        {
-                            half4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; e++)
-                            {
-                                const float v = acc[rr][q * 4 + e] + bq[q][e];
-                                o[e] = (_Float16)fmaxf(v, v * slope);
-                            }
-                            *reinterpret_cast<half4*>(ob + (wrow * 4 + rr) * (32 * 64) + ((q ^ swz) << 4)) = o;
-                        }
-                }
-                else if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
-                else if (EPI == 3) {}
+                if (EPI == 0) conv_epilogue(a, acc, bq, ntw, it.slot, it.y0, it.x0, it.H, it.W, wrow, l32, hi);
                 else if ((EPI == 1 || EPI == 2) && !(a.dbg & 64))
                 { // coalesced stores through a private LDS row of the patch that was just consumed
                     char* flags = smem + 2 * STAGE + 256;
@@ -903,23 +790,17 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_pipe(const 
                 for (int e = 0; e < 16; e++) acc[rr][e] = 0.f;
         }
     }
-    if (OUTBOX) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // B_S: hand the last outbox to the loaders
 }
+
+constexpr size_t pipe_lds(int NT) { return 2 * (size_t(kPatchLds) + size_t(9 * NT * 32 * 64)) + 256 + 64; } // two stages + bias + flags
 
 template <int NT, bool UPS, int EPI>
 static void launch_conv_pipe_t(const ConvArgs& a, int ncu, hipStream_t st)
 {
-    const size_t lds = 2 * (size_t(kPatchLds) + size_t(9 * NT * 32 * 64)) + 256 + 64 + (EPI == 3 ? 32768 : 0); // two stages + bias + flags (+ outbox)
-    static bool attr_set = false;
-    if (!attr_set)
-    {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe<NT, UPS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        attr_set = true;
-    }
     int grid = ncu & ~7; // multiple of 8 (XCD mapping)
     const int per = (a.nitems + 7) / 8;
     if (per * 8 < grid) grid = per * 8;
-    hipLaunchKernelGGL((conv3x3_pipe<NT, UPS, EPI>), dim3(grid), dim3((4 * NT + 4) * 64), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_pipe<NT, UPS, EPI>), dim3(grid), dim3((4 * NT + 4) * 64), pipe_lds(NT), st, a);
 }
 
 void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st)
@@ -933,12 +814,10 @@ void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st)
         if (a.res1_kind == 0 && a.res2_kind == 0) epi = 1;
         else if (a.res1_kind == 1 && (a.res2_kind == 0 || a.res2_kind == 1)) epi = 2;
     }
-    if (epi == 1 && nt == 1 && a.n0 + a.n1 >= 2 && !(a.dbg & 32)) epi = 3; // outbox: stores by the loader waves
 #define RSR_PIPE(NT_, UPS_)                                                   \
     do                                                                        \
     {                                                                         \
-        if (epi == 3) launch_conv_pipe_t<1, UPS_, 3>(a, ncu, st);             \
-        else if (epi == 1) launch_conv_pipe_t<NT_, UPS_, 1>(a, ncu, st);      \
+        if (epi == 1) launch_conv_pipe_t<NT_, UPS_, 1>(a, ncu, st);           \
         else if (epi == 2) launch_conv_pipe_t<NT_, UPS_, 2>(a, ncu, st);      \
         else launch_conv_pipe_t<NT_, UPS_, 0>(a, ncu, st);                    \
     } while (0)
@@ -1149,7 +1028,6 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
 
     int r = 0, ck = 0, slot3 = 0;
     WorkItem it = items[0];
-    for (int k = (j & 3) * a.stagger; k > 0; k -= 64) __builtin_amdgcn_s_sleep(64); // de-phase the workgroups (see ConvArgs::stagger)
     const bool tracing = a.trace && blockIdx.x == 0 && wave == 0;
 #define RSR_LOAD_STEP(X, Wf, T)                                                                                     \
     {                                                                                                                \
@@ -1411,12 +1289,6 @@ static bool launch_conv_ring_t(const ConvArgs& a, int ncu, hipStream_t st)
     const int nj = grid / 8, nmine_max = (per + nj - 1) / nj;
     const size_t fixed = size_t(kRingDepth) * kPatchLds + 2 * size_t(9 * NT * 32 * 64) + 256;
     if (fixed + sizeof(WorkItem) > 160 * 1024) return false; // 64 output channels: two weight images do not fit, use conv3x3_pipe
-    static bool attr_set = false;
-    if (!attr_set)
-    {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring<NT, UPS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     // The workgroup keeps its work-item descriptors in LDS; a list that does not fit (the 4x level has 16x the blocks) is
     // walked in several launches -- they read the same finished input and write disjoint blocks, stream order suffices.
     const int cap_items = int((160 * 1024 - fixed) / sizeof(WorkItem));
@@ -1458,12 +1330,6 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st)
 {
     const int per = (a.nitems + 7) / 8;
     const size_t lds = size_t(kPatchLds) + size_t(9 * NT * 32 * 64);
-    static bool attr_set = false; // > 64 KiB dynamic LDS needs the opt-in once per kernel
-    if (!attr_set)
-    {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NT, UPS, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        attr_set = true;
-    }
     hipLaunchKernelGGL((conv3x3_mfma<NT, UPS, DMA>), dim3(per * 8), dim3(kThreads), lds, st, a);
 }
 
@@ -1483,6 +1349,37 @@ void launch_conv(const ConvArgs& a, int nt, bool dma, hipStream_t st)
     case 6: launch_conv_t<2, true, false>(a, st); break;
     default: launch_conv_t<2, true, true>(a, st); break;
     }
+}
+
+// > 64 KiB of dynamic LDS needs an opt-in per kernel AND per device (a process-wide "done" flag would leave the
+// second GPU of a multi-device process without it): the engine calls this once per context, on its own device.
+hipError_t kernels_init_device()
+{
+    hipError_t e = hipSuccess;
+#define RSR_ATTR(K, BYTES)                                                                                           \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, int(BYTES));
+#define RSR_COMMA ,
+#define RSR_PIPE_ATTRS(NT, UPS)                                                                                      \
+    RSR_ATTR(conv3x3_pipe<NT RSR_COMMA UPS RSR_COMMA 0>, pipe_lds(NT))                                               \
+    RSR_ATTR(conv3x3_pipe<NT RSR_COMMA UPS RSR_COMMA 1>, pipe_lds(NT))                                               \
+    RSR_ATTR(conv3x3_pipe<NT RSR_COMMA UPS RSR_COMMA 2>, pipe_lds(NT))
+    RSR_PIPE_ATTRS(1, false) RSR_PIPE_ATTRS(1, true) RSR_PIPE_ATTRS(2, false) RSR_PIPE_ATTRS(2, true)
+#define RSR_RING_ATTRS(UPS)                                                                                          \
+    RSR_ATTR(conv3x3_ring<1 RSR_COMMA UPS RSR_COMMA 0>, 160 * 1024)                                                  \
+    RSR_ATTR(conv3x3_ring<1 RSR_COMMA UPS RSR_COMMA 1>, 160 * 1024)                                                  \
+    RSR_ATTR(conv3x3_ring<1 RSR_COMMA UPS RSR_COMMA 2>, 160 * 1024)
+    RSR_RING_ATTRS(false) RSR_RING_ATTRS(true)
+#define RSR_MFMA_ATTRS(NT, UPS)                                                                                      \
+    RSR_ATTR(conv3x3_mfma<NT RSR_COMMA UPS RSR_COMMA false>, size_t(kPatchLds) + size_t(9 * NT * 32 * 64))           \
+    RSR_ATTR(conv3x3_mfma<NT RSR_COMMA UPS RSR_COMMA true>, size_t(kPatchLds) + size_t(9 * NT * 32 * 64))
+    RSR_MFMA_ATTRS(1, false) RSR_MFMA_ATTRS(1, true) RSR_MFMA_ATTRS(2, false) RSR_MFMA_ATTRS(2, true)
+#undef RSR_MFMA_ATTRS
+#undef RSR_RING_ATTRS
+#undef RSR_PIPE_ATTRS
+#undef RSR_COMMA
+#undef RSR_ATTR
+    if (e == hipSuccess) e = flow_init_device();
+    return e;
 }
 
 // =============================================================================================
@@ -1536,11 +1433,14 @@ __global__ __launch_bounds__(256) void preproc_tiles(const PreArgs a)
         case 6: oy = t.tw - 1 - gx; ox = t.th - 1 - gy; ow = t.th; break;
         case 7: oy = t.tw - 1 - gx; ox = gy; ow = t.th; break;
         }
-        char* dst = static_cast<char*>(a.in_plane) + (long long)(t.slot0 + k) * a.slot_stride + ((long long)oy * ow + ox) * 64;
+        char* dst = static_cast<char*>(a.in_plane) + (long long)(t.slot0 + k) * a.slot_stride + ((long long)oy * ow + ox) * (a.plane_ch * 2);
         *reinterpret_cast<half8*>(dst) = v0;
         *reinterpret_cast<uint4*>(dst + 16) = z;
-        *reinterpret_cast<uint4*>(dst + 32) = z;
-        *reinterpret_cast<uint4*>(dst + 48) = z;
+        if (a.plane_ch == 32)
+        {
+            *reinterpret_cast<uint4*>(dst + 32) = z;
+            *reinterpret_cast<uint4*>(dst + 48) = z;
+        }
     }
 }
 
@@ -1763,7 +1663,7 @@ void launch_postproc_shader(const uint16_t* const bottom[8], int nbottom, int w,
                        offset_x, gx_max, crop_x, crop_y, channels, bgr);
 }
 
-__global__ __launch_bounds__(256) void planar3_to_plane(const uint16_t* planar, int w, int h, void* plane)
+__global__ __launch_bounds__(256) void planar3_to_plane(const uint16_t* planar, int w, int h, void* plane, int plane_ch)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)w * h) return;
@@ -1772,17 +1672,34 @@ __global__ __launch_bounds__(256) void planar3_to_plane(const uint16_t* planar, 
     v0.x = (uint32_t)planar[i] | ((uint32_t)planar[hw + i] << 16);
     v0.y = (uint32_t)planar[2 * hw + i];
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    uint4* d = reinterpret_cast<uint4*>(static_cast<char*>(plane) + i * 64);
+    uint4* d = reinterpret_cast<uint4*>(static_cast<char*>(plane) + i * (plane_ch * 2));
     d[0] = v0;
     d[1] = z;
-    d[2] = z;
-    d[3] = z;
+    if (plane_ch == 32)
+    {
+        d[2] = z;
+        d[3] = z;
+    }
 }
 
-void launch_planar3_to_plane(const uint16_t* planar, int w, int h, void* plane, hipStream_t st)
+void launch_planar3_to_plane(const uint16_t* planar, int w, int h, void* plane, int plane_ch, hipStream_t st)
 {
     const long long n = (long long)w * h;
-    hipLaunchKernelGGL(planar3_to_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, planar, w, h, plane);
+    hipLaunchKernelGGL(planar3_to_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, planar, w, h, plane, plane_ch);
+}
+
+// Zero the 64-byte guard in front of `count` planes spaced `stride` bytes apart (see Engine::ensure_workspace).
+__global__ __launch_bounds__(256) void zero_guards(char* first_guard, long long stride, long long count)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x; // one 16-byte piece per thread
+    if (i >= count * 4) return;
+    *reinterpret_cast<uint4*>(first_guard + (i >> 2) * stride + (i & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+}
+
+void launch_zero_guards(void* first_guard, long long stride, long long count, hipStream_t st)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(zero_guards, dim3((unsigned)((count * 4 + 255) / 256)), dim3(256), 0, st, static_cast<char*>(first_guard), stride, count);
 }
 
 } // namespace rsr

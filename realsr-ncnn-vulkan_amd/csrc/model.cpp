@@ -439,22 +439,22 @@ namespace {
 size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 } // namespace
 
-size_t packed_size(const Model& m)
+size_t packed_size(const Model& m, bool with_w32)
 {
     size_t off = align256(sizeof(PackedHeader) + m.convs.size() * sizeof(PackedConv));
     for (const ConvRec& c : m.convs)
     {
         const size_t np = size_t((c.cin + 31) / 32), nt = size_t((c.cout + 31) / 32);
-        off = align256(off + np * 9 * nt * 32 * 64);
+        if (with_w32) off = align256(off + np * 9 * nt * 32 * 64);
         off = align256(off + nt * 32 * 4);
-        off = align256(off + np * 18 * nt * 1024); // fragment-major copy
+        off = align256(off + 2 * np * 9 * nt * 32 * 32);
     }
     return off;
 }
 
-int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
+int pack_model(const Model& m, void* dst, size_t cap, std::string& err, bool with_w32)
 {
-    const size_t need = packed_size(m);
+    const size_t need = packed_size(m, with_w32);
     if (cap < need)
     {
         err = "packed blob buffer too small";
@@ -464,8 +464,9 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
     std::memset(base, 0, need);
     PackedHeader* H = reinterpret_cast<PackedHeader*>(base);
     H->magic = kPackedMagic;
-    H->version = 2;
+    H->version = kPackedVersion;
     H->nconv = uint32_t(m.convs.size());
+    H->flags = with_w32 ? 1u : 0u;
     H->total_bytes = need;
     PackedConv* T = reinterpret_cast<PackedConv*>(base + sizeof(PackedHeader));
     size_t off = align256(sizeof(PackedHeader) + m.convs.size() * sizeof(PackedConv));
@@ -480,75 +481,106 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
         P.nplanes = uint32_t(np);
         P.nt = uint32_t(nt);
         P.slope = c.slope;
-        P.w_off = off;
-        uint16_t* W = reinterpret_cast<uint16_t*>(base + off);
+        auto wt = [&](int n, int ic, int tap) -> uint16_t {
+            float v = 0.f;
+            if (n < c.cout && ic < c.cin) v = c.weight[(size_t(n) * c.cin + ic) * 9 + tap];
+            return f32_to_f16(v);
+        };
         const int rows = 9 * nt * 32;
-        for (int ck = 0; ck < np; ck++)
-            for (int tap = 0; tap < 9; tap++)
-                for (int n = 0; n < nt * 32; n++)
-                {
-                    const int row = tap * nt * 32 + n;
-                    uint16_t* R = W + (size_t(ck) * rows + row) * 32;
-                    for (int slot = 0; slot < 4; slot++)
+        P.w_off = 0;
+        if (with_w32)
+        {
+            P.w_off = off;
+            uint16_t* W = reinterpret_cast<uint16_t*>(base + off);
+            for (int ck = 0; ck < np; ck++)
+                for (int tap = 0; tap < 9; tap++)
+                    for (int n = 0; n < nt * 32; n++)
                     {
-                        const int pslot = slot ^ ((row >> 2) & 3);
-                        for (int e = 0; e < 8; e++)
+                        const int row = tap * nt * 32 + n;
+                        uint16_t* R = W + (size_t(ck) * rows + row) * 32;
+                        for (int slot = 0; slot < 4; slot++)
                         {
-                            const int ic = ck * 32 + slot * 8 + e;
-                            float v = 0.f;
-                            if (n < c.cout && ic < c.cin) v = c.weight[(size_t(n) * c.cin + ic) * 9 + tap];
-                            R[pslot * 8 + e] = f32_to_f16(v);
+                            const int pslot = slot ^ ((row >> 2) & 3);
+                            for (int e = 0; e < 8; e++) R[pslot * 8 + e] = wt(n, ck * 32 + slot * 8 + e, tap);
                         }
                     }
-                }
-        off = align256(off + size_t(np) * rows * 64);
+            off = align256(off + size_t(np) * rows * 64);
+        }
         P.b_off = off;
         float* B = reinterpret_cast<float*>(base + off);
         for (int n = 0; n < c.cout; n++) B[n] = c.bias[size_t(n)];
         off = align256(off + size_t(nt) * 32 * 4);
-        P.wf_off = off;
-        uint16_t* F = reinterpret_cast<uint16_t*>(base + off);
-        for (int ck = 0; ck < np; ck++)
-            for (int dx = 0; dx < 3; dx++)
-                for (int cb = 0; cb < 2; cb++)
-                    for (int dy = 0; dy < 3; dy++)
-                        for (int t = 0; t < nt; t++)
-                        {
-                            uint16_t* blk = F + ((((size_t(ck) * 3 + dx) * 2 + cb) * 3 + dy) * nt + t) * 512;
-                            for (int lane = 0; lane < 64; lane++)
-                                for (int e8 = 0; e8 < 8; e8++)
-                                {
-                                    const int n = t * 32 + (lane & 31), ic = ck * 32 + cb * 16 + (lane >> 5) * 8 + e8;
-                                    float v = 0.f;
-                                    if (n < c.cout && ic < c.cin) v = c.weight[(size_t(n) * c.cin + ic) * 9 + dy * 3 + dx];
-                                    blk[lane * 8 + e8] = f32_to_f16(v);
-                                }
-                        }
-        off = align256(off + size_t(np) * 18 * nt * 1024);
+        P.w16_off = off;
+        uint16_t* W16 = reinterpret_cast<uint16_t*>(base + off);
+        for (int pl = 0; pl < 2 * np; pl++)
+            for (int tap = 0; tap < 9; tap++)
+                for (int n = 0; n < nt * 32; n++)
+                {
+                    uint16_t* R = W16 + (size_t(pl) * rows + size_t(tap) * nt * 32 + n) * 16;
+                    for (int slot = 0; slot < 2; slot++)
+                    {
+                        const int pslot = slot ^ ((n >> 3) & 1);
+                        for (int e = 0; e < 8; e++) R[pslot * 8 + e] = wt(n, pl * 16 + slot * 8 + e, tap);
+                    }
+                }
+        off = align256(off + size_t(2 * np) * rows * 32);
     }
     return RSR_OK;
 }
 
-int check_packed(const void* blob, size_t bytes, std::string& err)
+void canonical_conv(int index, int& cin, int& cout, int& act)
 {
-    if (!blob || bytes < sizeof(PackedHeader))
+    // x4.param order: conv_first | 69 x {64->32, 96->32, 128->32, 160->32 (LeakyReLU), 192->64} | trunk_conv |
+    // upconv1, upconv2, HRconv (LeakyReLU) | conv_last
+    act = 0;
+    if (index == 0) { cin = 3; cout = kNF; return; }
+    if (index <= kNumRDB * 5)
+    {
+        const int k = (index - 1) % 5;
+        cin = kNF + k * kGC;
+        cout = k < 4 ? kGC : kNF;
+        act = k < 4 ? 2 : 0;
+        return;
+    }
+    const int t = index - 1 - kNumRDB * 5; // 0 trunk, 1 up1, 2 up2, 3 HR, 4 last
+    cin = kNF;
+    cout = t == 4 ? 3 : kNF;
+    act = (t >= 1 && t <= 3) ? 2 : 0;
+}
+
+size_t packed_table_bytes() { return sizeof(PackedHeader) + size_t(kNumConvs) * sizeof(PackedConv); }
+
+int check_packed(const void* head, size_t head_bytes, size_t total_bytes, std::string& err)
+{
+    if (!head || head_bytes < packed_table_bytes() || total_bytes < head_bytes)
     {
         err = "packed blob too small";
         return RSR_E_FORMAT;
     }
-    const PackedHeader* H = static_cast<const PackedHeader*>(blob);
-    if (H->magic != kPackedMagic || H->version != 2 || H->nconv != uint32_t(kNumConvs) || H->total_bytes != bytes)
+    const PackedHeader* H = static_cast<const PackedHeader*>(head);
+    if (H->magic != kPackedMagic || H->version != kPackedVersion || H->nconv != uint32_t(kNumConvs) || H->total_bytes != total_bytes)
     {
-        err = "packed blob header mismatch";
+        err = "packed blob header mismatch (magic / version / conv count / size)";
         return RSR_E_FORMAT;
     }
-    const PackedConv* T = reinterpret_cast<const PackedConv*>(static_cast<const unsigned char*>(blob) + sizeof(PackedHeader));
-    for (uint32_t i = 0; i < H->nconv; i++)
-        if (T[i].w_off >= bytes || T[i].b_off >= bytes || T[i].wf_off >= bytes || T[i].nplanes == 0 || T[i].nt == 0 || T[i].nt > 2)
+    const bool w32 = (H->flags & 1u) != 0;
+    const PackedConv* T = reinterpret_cast<const PackedConv*>(static_cast<const unsigned char*>(head) + sizeof(PackedHeader));
+    for (int i = 0; i < kNumConvs; i++)
+    {
+        const PackedConv& c = T[i];
+        int cin, cout, act;
+        canonical_conv(i, cin, cout, act);
+        const uint64_t np = uint64_t((cin + 31) / 32), nt = uint64_t((cout + 31) / 32);
+        bool ok = int(c.cin) == cin && int(c.cout) == cout && int(c.act) == act && c.nplanes == np && c.nt == nt;
+        auto inside = [&](uint64_t off, uint64_t size) { return off >= packed_table_bytes() && (off & 255) == 0 && off <= total_bytes && size <= total_bytes - off; };
+        ok = ok && inside(c.b_off, nt * 32 * 4) && inside(c.w16_off, 2 * np * 9 * nt * 32 * 32);
+        ok = ok && (w32 ? inside(c.w_off, np * 9 * nt * 32 * 64) : c.w_off == 0);
+        if (!ok)
         {
-            err = "packed blob conv table corrupt";
+            err = "packed blob conv table corrupt at convolution " + std::to_string(i);
             return RSR_E_FORMAT;
         }
+    }
     return RSR_OK;
 }
 

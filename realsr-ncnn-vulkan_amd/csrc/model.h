@@ -54,37 +54,45 @@ int read_bin(const std::string& path, Model& m, std::string& err);
 int load_model(const std::string& param, const std::string& bin, Model& m, std::string& err);
 
 // ---- packed blob ---------------------------------------------------------------------------
-// One relocatable byte blob holding every conv's weights in the exact LDS image the MFMA kernel
-// stages (see kernels.hip): per conv, per 32-input-channel chunk:
-//     [tap 0..8][cout row 0..NT*32-1][32 cin] fp16, 64 B per row, the four 16-B slots of a row
-//     XOR-swizzled with ((row_index >> 2) & 3), row_index = tap*NT*32 + cout
-// followed by NT*32 fp32 biases.  Cin is zero-padded to a multiple of 32 (conv_first 3 -> 32),
-// Cout to a multiple of 32 (conv_last 3 -> 32).
+// One relocatable byte blob holding every conv's weights in the exact LDS images the MFMA kernels stage:
+//   w16 (conv3x3_flow, 16-channel planes): per conv, per 16-input-channel plane
+//       [tap 0..8][cout row 0..NT*32-1][16 cin] fp16, 32 B per row, the two 16-B slots of a row swapped when (cout>>3)&1
+//   w32 (round-1 kernels conv3x3_ring / _pipe / _mfma, 32-channel planes; kept as second implementations for the
+//       A/B tests): per conv, per 32-input-channel chunk [tap][cout row][32 cin], 64 B per row, the four 16-B slots
+//       XOR-swizzled with ((row_index >> 2) & 3), row_index = tap*NT*32 + cout
+// followed by NT*32 fp32 biases.  Cin is zero-padded to a multiple of 32 (conv_first 3 -> 32: two 16-channel planes,
+// the second all zero), Cout to a multiple of 32 (conv_last 3 -> 32).  pack_model(.., with_w32 = false) leaves the
+// w32 images out (w_off = 0): that is what travels in the multi-GPU broadcast.
 struct PackedHeader
 {
     uint32_t magic;   // 'RSRP'
-    uint32_t version; // 2
+    uint32_t version; // 3
     uint32_t nconv;
-    uint32_t reserved;
+    uint32_t flags;   // bit 0: w32 images present
     uint64_t total_bytes;
 };
 struct PackedConv
 {
     uint32_t cin, cout;     // true channel counts
     uint32_t act;           // 0 / 2
-    uint32_t nplanes;       // ceil(cin/32)
+    uint32_t nplanes;       // ceil(cin/32): 32-channel chunks (= half the number of 16-channel planes)
     uint32_t nt;            // ceil(cout/32)
     float slope;
-    uint64_t w_off, b_off;  // byte offsets from blob start (256-B aligned)
-    uint64_t wf_off;        // fragment-major copy of the weights (conv3x3_ring reads MFMA A-fragments straight from L2):
-                            // [chunk][dx 0..2][cb 0..1][dy 0..2][nt][lane 0..63][8 halfs]; lane = hi*32 + n holds
-                            // W[cout nt*32+n][cin chunk*32 + cb*16 + hi*8 .. +8][tap dy*3+dx] -> one coalesced 1 KiB per fragment
+    uint64_t w_off, b_off;  // byte offsets from blob start (256-B aligned); w_off = 0 when the w32 images are absent
+    uint64_t w16_off;       // 16-channel-plane images
 };
+constexpr uint32_t kPackedVersion = 3;
 constexpr uint32_t kPackedMagic = 0x50525352u; // "RSRP"
 
-size_t packed_size(const Model& m);
-int pack_model(const Model& m, void* dst, size_t cap, std::string& err);
-int check_packed(const void* blob, size_t bytes, std::string& err);
+size_t packed_size(const Model& m, bool with_w32 = true);
+int pack_model(const Model& m, void* dst, size_t cap, std::string& err, bool with_w32 = true);
+// Full validation of a blob that may come from anywhere (a broadcast, a file): header, every offset + extent inside the
+// blob, and the conv table equal to the canonical RRDBNet schedule (cin/cout/act per index) the engine hard-wires.
+// Only the header + table (first packed_table_bytes() bytes) are dereferenced.
+int check_packed(const void* head, size_t head_bytes, size_t total_bytes, std::string& err);
+size_t packed_table_bytes();
+// cin / cout of convolution `index` (0..350) in x4.param order
+void canonical_conv(int index, int& cin, int& cout, int& act);
 
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);

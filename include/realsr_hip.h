@@ -146,6 +146,14 @@ int rsr_net_forward(rsr_ctx* ctx, const uint16_t* in, int w, int h, uint16_t* ou
 int rsr_conv3x3(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, int upsample2x, const float* weight,
                 const float* bias, int cout, int lrelu, uint16_t* out);
 
+/* The residual epilogues of the graph on one convolution (what Eltwise / BinaryOp do behind a Convolution in x4.param):
+ *   v = s1*(conv + b)  [+ in[0:cout] when own_input_residual: RDB conv5, x4.param:17-18]
+ *   [v = s2*v + res when own_input_residual and res: every third RDB, x4.param:47]
+ *   [v = v + res when !own_input_residual and res: trunk_conv + global skip, x4.param:994-995]
+ * res: planar fp16 [cout][h][w] or NULL; cout 32 or 64; no upsampling, no activation.  Host pointers. */
+int rsr_conv3x3_res(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, const float* weight, const float* bias, int cout,
+                    float s1, int own_input_residual, const uint16_t* res, float s2, uint16_t* out);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct rsr_profile
 {

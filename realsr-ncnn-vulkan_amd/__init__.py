@@ -24,7 +24,7 @@ EXPORTS = [
     "rsr_model_pack", "rsr_load_packed", "rsr_model_info", "rsr_preproc", "rsr_preproc_tta", "rsr_postproc",
     "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times", "rsr_get_trace",
     "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_model_pack_ex", "rsr_host_alloc", "rsr_host_free",
-    "rsr_set_progress_callback",
+    "rsr_set_progress_callback", "rsr_conv3x3_res",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -97,6 +97,7 @@ def lib():
     L.rsr_postproc_tta.argtypes = [vp, C.POINTER(vp), ip, ip, vp, ip, ip, ip, ip, ip, ip, ip]
     L.rsr_net_forward.argtypes = [vp, vp, ip, ip, vp]
     L.rsr_conv3x3.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp]
+    L.rsr_conv3x3_res.argtypes = [vp, vp, ip, ip, ip, vp, vp, ip, C.c_float, ip, vp, C.c_float, vp]
     L.rsr_set_profiling.argtypes = [vp, ip]
     L.rsr_get_profile.argtypes = [vp, C.POINTER(Profile), ip]
     L.rsr_get_conv_times.argtypes = [vp, C.POINTER(C.c_double), ip, ip]
@@ -248,6 +249,21 @@ class RealSR:
         s = 2 if upsample2x else 1
         out = np.empty((cout, h * s, w * s), dtype=np.float16)
         self._ck(self._L.rsr_conv3x3(self._h, _p(x), cin, h, w, int(upsample2x), _p(weight), _p(bias), cout, int(lrelu), _p(out)))
+        return out
+
+    def conv3x3_res(self, x, weight, bias, s1, own_input_residual=False, res=None, s2=1.0):
+        """v = s1*(conv+b) [+ x[:cout]] [; v = s2*v + res | v + res]  -- see rsr_conv3x3_res."""
+        x = np.ascontiguousarray(x, dtype=np.float16)
+        weight = np.ascontiguousarray(weight, dtype=np.float32)
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+        cin, h, w = x.shape
+        cout = weight.shape[0]
+        if res is not None:
+            res = np.ascontiguousarray(res, dtype=np.float16)
+            assert res.shape == (cout, h, w)
+        out = np.empty((cout, h, w), dtype=np.float16)
+        self._ck(self._L.rsr_conv3x3_res(self._h, _p(x), cin, h, w, _p(weight), _p(bias), cout, float(s1),
+                                         int(bool(own_input_residual)), _p(res), float(s2), _p(out)))
         return out
 
     def preproc(self, band, outw, outh, pad_top, pad_left, crop_x, crop_y, alphaw=0, alphah=0):

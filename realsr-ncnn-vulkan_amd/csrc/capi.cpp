@@ -291,6 +291,14 @@ int rsr_conv3x3(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, int ups
     return ctx->e.conv_test(in, cin, h, w, upsample2x, weight, bias, cout, lrelu, out);
 }
 
+int rsr_conv3x3_res(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, const float* weight, const float* bias, int cout,
+                    float s1, int own_input_residual, const uint16_t* res, float s2, uint16_t* out)
+{
+    if (!ctx) return RSR_E_ARG;
+    if (s1 == 0.f) return Engine::fail(RSR_E_ARG, "s1 must be non-zero");
+    return ctx->e.conv_test(in, cin, h, w, 0, weight, bias, cout, 0, out, s1, own_input_residual, res, s2);
+}
+
 int rsr_set_profiling(rsr_ctx* ctx, int enable)
 {
     if (!ctx) return RSR_E_ARG;

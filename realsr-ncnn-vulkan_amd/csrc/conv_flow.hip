@@ -27,6 +27,10 @@
 // loaders' vmcnt bookkeeping nor need LDS), so a launch never has to be split.
 #include "kernels.h"
 
+#ifndef RSR_EXP
+#define RSR_EXP 0 // experiment switch of variant builds (tools/build_variant.sh); 0 in the product
+#endif
+
 namespace rsr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -35,6 +39,10 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+// The transpose scratch is written as half4 and read back as u32x4: without may_alias, type-based alias analysis lets
+// the compiler move row k+1's writes above row k's read-back (seen on hardware as a run-to-run varying corruption).
+typedef half4 __attribute__((may_alias)) half4_scr;
+typedef u32x4 __attribute__((may_alias)) u32x4_scr;
 
 namespace {
 
@@ -77,6 +85,16 @@ __device__ __forceinline__ WorkItem load_item(const WorkItem* items, int idx)
     it.W = __builtin_amdgcn_readfirstlane(v[4]);
     it.pad0 = it.pad1 = it.pad2 = 0;
     return it;
+}
+
+// A pointer the compiler can PROVE wave-uniform (buffer resources built from it need no waterfall loop).  readfirstlane
+// returns a signed int: widen through unsigned, or a low half with bit 31 set sign-extends into the high half.
+__device__ __forceinline__ char* uniform_ptr(const void* p)
+{
+    const unsigned long long b = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return reinterpret_cast<char*>((unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
 #define RSR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
@@ -297,12 +315,12 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 else v = __builtin_amdgcn_fmed3f(v, v * slope, pinf0); // = max(v, slope*v), one instruction
                 o[e] = (_Float16)v;
             }
-            *reinterpret_cast<half4*>(wr + (q >> 1) * 1024 + (((q & 1) << 4) ^ scr_wx)) = o;
+            *reinterpret_cast<half4_scr*>(wr + (q >> 1) * 1024 + (((q & 1) << 4) ^ scr_wx)) = o;
         }
     };
     auto row_from_lds = [&](u32x4 (&tq)[2], int n) {
 #pragma unroll
-        for (int p = 0; p < 2; p++) tq[p] = *reinterpret_cast<const u32x4*>(scr + n * 2048 + p * 1024 + scr_r);
+        for (int p = 0; p < 2; p++) tq[p] = *reinterpret_cast<const u32x4_scr*>(scr + n * 2048 + p * 1024 + scr_r);
     };
     // residual stages in the transposed domain (lane = 8 consecutive channels of one pixel): v = t + r1, v = v*s2 + r2
     auto row_residual = [&](u32x4 (&tq)[2], const OutDesc& o, int rr, int n) {
@@ -332,14 +350,16 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // dropped by the buffer range check (null resource / out-of-range offset), so the epilogue is branch-free
     auto row_store = [&](const u32x4 (&tq)[2], const OutDesc& o, int rr, int n) {
         const int y = o.y0 + rr;
-        const unsigned long long b = (unsigned long long)o.base;
-        char* ub = reinterpret_cast<char*>((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)b) |
-                                           ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32));
+        char* ub = uniform_ptr(o.base);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
         const unsigned pstride = unsigned(a.out16.plane_stride);
+        // The row / plane offset travels in the VGPR offset, soffset = 0: gfx950 needs 2 wait states between a > 64-bit
+        // buffer store and a VALU write of its data registers ALSO when soffset is an SGPR, but hipcc only pads the
+        // soffset-less form (seen as garbage in dword 0 of lanes 12-15 of every 16 -- the lanes whose data is read last --
+        // whenever the next row's arithmetic reused the registers right behind the store).  Out-of-image lanes keep bit 31.
 #pragma unroll
         for (int p = 0; p < 2; p++)
-            __builtin_amdgcn_raw_buffer_store_b128(tq[p], rs, o.voff, unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(tq[p], rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride), 0, 0);
     };
     // conv_last (EPI 0): channels 0..2 of n-tile 0 -> planar fp16 [3][H][W]
     auto planar_store = [&](const f32x16 (&acc)[4][NTW], const WorkItem& it) {
@@ -394,7 +414,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // hidden load can only make them over-wait by one.)
 #define RSR_STEP(ACC, WCUR, WNXT, NXB, NWB, NDX, FIRST, BAR, ITEMQ, HK)                                              \
     {                                                                                                                \
-        if ((BAR) && (ITEMQ))                                                                                        \
+        if ((BAR) && (ITEMQ))                                                                        \
         {                                                                                                            \
             const WorkItem* ip_ = a.items + (first + min(r + 2, nmine - 1) * nj);                                    \
             asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(item_q) : "s"(ip_));                                    \
@@ -604,62 +624,60 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         asm volatile("" : "+s"(pinf)); // opaque: med3(v, s*v, +inf) stays ONE instruction (a literal folds to maxnum + canonicalize)
         auto row_store1 = [&](const u32x4& v, const OutDesc& o, int rr, int p) {
             const int y = o.y0 + rr;
-            const unsigned long long b = (unsigned long long)o.base;
-            char* ub = reinterpret_cast<char*>((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)b) |
-                                               ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32));
+            char* ub = uniform_ptr(o.base);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, o.voff, unsigned(y) * unsigned(o.W * kFPx) + unsigned(p) * unsigned(a.out16.plane_stride), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(p) * unsigned(a.out16.plane_stride)), 0, 0);
         };
 #define RSR_HK_S0(c) RSR_HK_S0_##c
 #define RSR_HK_S0_0 __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][0], v1_ = RSR_OLD[0][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][2], v1_ = RSR_OLD[0][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][4], v1_ = RSR_OLD[0][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][4], v1_ = RSR_OLD[0][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][6], v1_ = RSR_OLD[0][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][8], v1_ = RSR_OLD[0][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][8], v1_ = RSR_OLD[0][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][10], v1_ = RSR_OLD[0][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][12], v1_ = RSR_OLD[0][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][12], v1_ = RSR_OLD[0][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][14], v1_ = RSR_OLD[0][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_10 __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_11 __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1(c) RSR_HK_S1_##c
 #define RSR_HK_S1_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][0], v1_ = RSR_OLD[1][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][2], v1_ = RSR_OLD[1][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][4], v1_ = RSR_OLD[1][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][4], v1_ = RSR_OLD[1][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][6], v1_ = RSR_OLD[1][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][8], v1_ = RSR_OLD[1][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][8], v1_ = RSR_OLD[1][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][10], v1_ = RSR_OLD[1][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][12], v1_ = RSR_OLD[1][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][12], v1_ = RSR_OLD[1][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][14], v1_ = RSR_OLD[1][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 0, 0); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 0, 1); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2(c) RSR_HK_S2_##c
 #define RSR_HK_S2_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][0], v1_ = RSR_OLD[2][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][2], v1_ = RSR_OLD[2][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][4], v1_ = RSR_OLD[2][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][4], v1_ = RSR_OLD[2][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][6], v1_ = RSR_OLD[2][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][8], v1_ = RSR_OLD[2][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][8], v1_ = RSR_OLD[2][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][10], v1_ = RSR_OLD[2][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][12], v1_ = RSR_OLD[2][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][12], v1_ = RSR_OLD[2][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][14], v1_ = RSR_OLD[2][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 1, 0); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 1, 1); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3(c) RSR_HK_S3_##c
 #define RSR_HK_S3_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][0], v1_ = RSR_OLD[3][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][2], v1_ = RSR_OLD[3][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][4], v1_ = RSR_OLD[3][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][4], v1_ = RSR_OLD[3][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][6], v1_ = RSR_OLD[3][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][8], v1_ = RSR_OLD[3][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][8], v1_ = RSR_OLD[3][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][10], v1_ = RSR_OLD[3][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][12], v1_ = RSR_OLD[3][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][12], v1_ = RSR_OLD[3][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][14], v1_ = RSR_OLD[3][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 2, 0); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 2, 1); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S4(c) RSR_HK_S4_##c

@@ -906,9 +906,11 @@ int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out)
 
 // one convolution with caller-supplied weights (layer-level parity hook, include/realsr_hip.h rsr_conv3x3)
 int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout,
-                      int lrelu, uint16_t* out)
+                      int lrelu, uint16_t* out, float s1, int own_res, const uint16_t* res, float s2)
 {
     if (!in || !weight || !bias || !out || cin < 1 || cout < 1 || cout > 64 || h < 1 || w < 1) return fail(RSR_E_ARG, "bad arguments");
+    const bool residual = s1 != 0.f;
+    if (residual && (ups || lrelu || (own_res && cin < cout) || (cout % 32))) return fail(RSR_E_ARG, "residual form: no upsampling / activation, cout 32 or 64");
     std::lock_guard<std::mutex> lk(mu);
     HIP_TRY(hipSetDevice(device));
     Model m;
@@ -933,17 +935,25 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     std::vector<uint16_t> hin(size_t(np) * ipl, 0), hout(size_t(npo) * opx * size_t(pch), 0);
     for (int ch = 0; ch < cin; ch++)
         for (size_t p = 0; p < ipx; p++) hin[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = in[size_t(ch) * ipx + p];
-    DevBuf d_w, d_in, d_out, d_tab;
+    std::vector<uint16_t> hres;
+    if (residual && res)
+    { // planar [cout][h][w] -> guarded planes like the input
+        hres.assign(size_t(npo) * ipl, 0);
+        for (int ch = 0; ch < cout; ch++)
+            for (size_t p = 0; p < ipx; p++) hres[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = res[size_t(ch) * ipx + p];
+    }
+    DevBuf d_w, d_in, d_out, d_tab, d_res;
     std::vector<WorkItem> items;
     for (int y0 = 0; y0 < H; y0 += kBlkH)
         for (int x0 = 0; x0 < W; x0 += kBlkW) items.push_back(WorkItem{0, y0, x0, H, W, 0, 0, 0});
     const TileDim td{h, w};
     auto cleanup = [&]() {
-        for (DevBuf* b : {&d_w, &d_in, &d_out, &d_tab})
+        for (DevBuf* b : {&d_w, &d_in, &d_out, &d_tab, &d_res})
             if (b->p) (void)hipFree(b->p);
     };
     if ((rc = ensure(d_w, pk.size())) != RSR_OK || (rc = ensure(d_in, hin.size() * 2)) != RSR_OK ||
-        (rc = ensure(d_out, hout.size() * 2)) != RSR_OK || (rc = ensure(d_tab, 256 + items.size() * sizeof(WorkItem))) != RSR_OK)
+        (rc = ensure(d_out, hout.size() * 2)) != RSR_OK || (rc = ensure(d_tab, 256 + items.size() * sizeof(WorkItem))) != RSR_OK ||
+        (!hres.empty() && (rc = ensure(d_res, hres.size() * 2)) != RSR_OK))
     {
         cleanup();
         return rc;
@@ -953,6 +963,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     if (he == hipSuccess) he = hipMemsetAsync(d_out.p, 0, hout.size() * 2, stream);
     if (he == hipSuccess) he = hipMemcpy(d_tab.p, &td, sizeof td, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(static_cast<char*>(d_tab.p) + 256, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice);
+    if (he == hipSuccess && !hres.empty()) he = hipMemcpy(d_res.p, hres.data(), hres.size() * 2, hipMemcpyHostToDevice);
     if (he == hipSuccess)
     {
         ConvArgs a;
@@ -966,6 +977,23 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         a.bias = reinterpret_cast<const float*>(static_cast<const char*>(d_w.p) + pc.b_off);
         a.lrelu = lrelu;
         a.s1 = a.s2 = 1.f;
+        if (residual)
+        { // the epilogue forms of RDB conv5 / trunk_conv (run_network)
+            a.s1 = s1;
+            if (own_res)
+            {
+                a.res1 = a.src0;
+                a.res1_kind = 1;
+                a.res1_in_acc = !(dbg & 4096);
+                a.res1_coef = 1.f / s1;
+            }
+            if (res)
+            {
+                const PlaneSrc rp{static_cast<char*>(d_res.p) + kGuard, 0, (long long)ipx * pch * 2 + kGuard};
+                if (own_res) { a.res2 = rp; a.res2_kind = 1; a.s2 = s2; }
+                else { a.res1 = rp; a.res1_kind = 1; } // trunk_conv form: v = s1*(conv+b) + res  (s2 unused)
+            }
+        }
         a.out16 = PlaneSrc{d_out.p, 0, (long long)opx * pch * 2};
         a.items = reinterpret_cast<const WorkItem*>(static_cast<const char*>(d_tab.p) + 256);
         a.nitems = int(items.size());

@@ -141,8 +141,9 @@ struct Engine
     int process_device(const void* d_in, int w, int h, int c, void* d_out, hipStream_t user_stream, bool sync);
     int process_host(const uint8_t* in, int w, int h, int c, uint8_t* out);
     int net_forward(const uint16_t* in, int w, int h, uint16_t* out);
+    // out = act(conv + b); with s1 != 0: v = s1*(conv + b) [+ in[0:cout] when own_res] [, v = s2*v + res when res]
     int conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout, int lrelu,
-                  uint16_t* out);
+                  uint16_t* out, float s1 = 0.f, int own_res = 0, const uint16_t* res = nullptr, float s2 = 1.f);
 
     // ---- internals (call with `mu` held unless noted) ----
     int plane_ch() const { return (kernel_version >= 4 && !trunk_fp32) ? 16 : 32; }

@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__((4 * NT + 4) * 64, NT + 1) void conv3x3_ring(const 
     {                                                                                                                \
         const int y_ = it.y0 + wrow * 4 + (RR);                                                                      \
         _Pragma("unroll") for (int k = 0; k < 2; k++)                                                                \
-            __builtin_amdgcn_raw_buffer_store_b128(T[k], y_ < it.H ? rs : rs0, voff[k], y_ * rowb, 0);               \
+            __builtin_amdgcn_raw_buffer_store_b128(T[k], y_ < it.H ? rs : rs0, voff[k] + y_ * rowb, 0, 0); /* soffset 0: see conv_flow.hip row_store */ \
     }
     for (int s = 0; s < S; s++)
     {

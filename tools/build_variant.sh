@@ -1,12 +1,17 @@
 #!/bin/bash
-# Build an experimental variant of librealsr_hip.so:  tools/build_variant.sh NAME "-DRSR_EXP_FOO=1 ..."
-# -> realsr-ncnn-vulkan_amd/lib/exp/NAME.so   (load with RSR_LIB=<path>; lib/ is git-ignored but travels to the GPU box)
+# Build an experimental variant of librealsr_hip.so:  tools/build_variant.sh NAME FILE "-DRSR_EXP=1 ..."
+# FILE = kernels | conv_flow.  -> realsr-ncnn-vulkan_amd/lib/exp/NAME.so   (load with RSR_LIB=<path>; lib/ is git-ignored
+# but travels to the GPU box)
 set -e
-NAME=$1; shift
+NAME=$1; FILE=$2; shift; shift
 D=$(cd "$(dirname "$0")/../realsr-ncnn-vulkan_amd" && pwd)
 make -s -C $D/csrc ../lib/librealsr_hip.so
 mkdir -p $D/lib/exp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden "$@" -c $D/csrc/kernels.hip -o $D/lib/exp/$NAME.kernels.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/lib/exp/$NAME.so $D/lib/exp/$NAME.kernels.o $D/lib/obj/engine.o $D/lib/obj/capi.o $D/lib/obj/model.o
-rm -f $D/lib/exp/$NAME.kernels.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden "$@" -c $D/csrc/$FILE.hip -o $D/lib/exp/$NAME.$FILE.o
+OBJS=""
+for o in kernels conv_flow engine capi model; do
+  if [ "$o" = "$FILE" ]; then OBJS="$OBJS $D/lib/exp/$NAME.$FILE.o"; else OBJS="$OBJS $D/lib/obj/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/lib/exp/$NAME.so $OBJS
+rm -f $D/lib/exp/$NAME.$FILE.o
 ls -la $D/lib/exp/$NAME.so

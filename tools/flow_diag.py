@@ -69,6 +69,40 @@ def sec_conv(sr):
     print("conv section: total bad =", total_bad)
 
 
+def sec_res(sr):
+    print("== residual epilogues (RDB conv5 / every-third / trunk forms) vs numpy")
+    rng = np.random.default_rng(3)
+    total_bad = 0
+    for (cin, cout, h, w) in [(192, 64, 20, 40), (64, 64, 33, 50), (192, 64, 70, 90)]:
+        x = rng.standard_normal((cin, h, w)).astype(np.float16)
+        wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float16).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        res = rng.standard_normal((cout, h, w)).astype(np.float16)
+        conv = oracle.conv3x3(x.astype(np.float32), wt, b, 0, 0.2)
+        forms = {"conv5": (0.2, True, None, 1.0, 0.2 * conv + x[:cout].astype(np.float32)),
+                 "conv5+rrdb": (0.2, True, res, 0.2, 0.2 * (0.2 * conv + x[:cout].astype(np.float32)) + res.astype(np.float32)),
+                 "trunk": (1.0, False, res, 1.0, conv + res.astype(np.float32))}
+        for kern, flags, dbg, ncu in ((3, 0, 0, 256), (4, 0, 0, 256), (4, 0, 4096, 256), (4, 1, 0, 256), (4, 1, 4096, 256), (4, 0, 0, 8), (4, 1, 0, 8)):
+            sr.set_option("kernel", kern)
+            sr.set_option("flow_flags", flags)
+            sr.set_option("dbg", dbg)
+            sr.set_option("num_cu", ncu)
+            for name, (s1, own, r, s2, ref) in forms.items():
+                got = sr.conv3x3_res(x, wt, b, s1, own_input_residual=own, res=r, s2=s2).astype(np.float32)
+                d = np.abs(got - ref)
+                bad = int((d > np.abs(ref) * 2.0 ** -9 + 2e-3).sum())
+                total_bad += bad
+                print("  %d->%d %dx%d kernel=%d flags=%d dbg=%d ncu=%d %-11s max|d|=%.3e bad=%d/%d%s" % (
+                    cin, cout, h, w, kern, flags, dbg, ncu, name, np.nanmax(d), bad, d.size, "  NaN!" if np.isnan(got).any() else ""), flush=True)
+                if bad:
+                    print("    per-channel bad:", (d > 1e-2).reshape(cout, -1).sum(1))
+    sr.set_option("kernel", 4)
+    sr.set_option("flow_flags", 0)
+    sr.set_option("dbg", 0)
+    sr.set_option("num_cu", 256)
+    print("res section: total bad =", total_bad)
+
+
 def sec_net(sr, net):
     print("== whole network on one tile vs oracle (pre-quantise, [0,1] units)")
     q = lambda v: np.clip(np.floor(v * 255.0 + 0.5), 0, 255)
@@ -176,7 +210,7 @@ def main():
     sr.load(pp, bp)
     for s in secs:
         try:
-            {"conv": lambda: sec_conv(sr), "net": lambda: sec_net(sr, net), "e2e": lambda: sec_e2e(net), "perf": sec_perf}[s]()
+            {"conv": lambda: sec_conv(sr), "res": lambda: sec_res(sr), "net": lambda: sec_net(sr, net), "e2e": lambda: sec_e2e(net), "perf": sec_perf}[s]()
         except Exception:
             traceback.print_exc()
             print("SECTION FAILED:", s, flush=True)

@@ -156,7 +156,7 @@ def write_param(path):
 # --------------------------------------------------------------------------------------------
 # weights
 # --------------------------------------------------------------------------------------------
-def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.12, bias_std=0.02):
+def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.12, bias_std=0.02, round_fp16=True):
     """Seeded synthetic weights, rounded to fp16-representable fp32.
 
     He-normal (fan_in, leaky slope 0.2) scaled by `rdb_gain` inside the dense blocks (ESRGAN initialises
@@ -182,8 +182,9 @@ def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.1
         b = rng.standard_normal(cout).astype(np.float32) * np.float32(bias_std)
         if i == len(specs) - 1:
             b = b + np.float32(0.5)
-        w = w.astype(np.float16).astype(np.float32)
-        b = b.astype(np.float16).astype(np.float32)
+        if round_fp16:  # False: full fp32 weights (a raw-fp32 x4.bin whose values the fp16 packer has to round)
+            w = w.astype(np.float16).astype(np.float32)
+            b = b.astype(np.float16).astype(np.float32)
         ws.append((w, b))
     return ws
 

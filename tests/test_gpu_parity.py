@@ -59,16 +59,47 @@ def test_conv3x3_layer_matches_oracle(sr, cin, cout, h, w, ups, lrelu):
         xr = xr.repeat(2, axis=1).repeat(2, axis=2)
     ref = oracle.conv3x3(xr, wt, b, 2 if lrelu else 0, 0.2)
     try:
-        for kernel, dma in ((3, 1), (2, 1), (1, 1), (1, 0)):  # conv3x3_ring, conv3x3_pipe, conv3x3_mfma with LDS-DMA / register staging
+        # conv3x3_flow (8 x 32 / 4 x 64 MFMA waves, with / without deferred epilogue), conv3x3_ring, conv3x3_pipe,
+        # conv3x3_mfma with LDS-DMA / register staging
+        for kernel, dma, flags in ((4, 1, 0), (4, 1, 3), (3, 1, 0), (2, 1, 0), (1, 1, 0), (1, 0, 0)):
             sr.set_option("kernel", kernel)
             sr.set_option("use_dma", dma)
+            sr.set_option("flow_flags", flags)
             got = sr.conv3x3(x, wt, b, lrelu=lrelu, upsample2x=ups).astype(np.float32)
             assert got.shape == ref.shape
-            assert (np.abs(got - ref) <= np.abs(ref) * 2.0 ** -10 + 1e-3).all(), "kernel=%d dma=%d max err %g" % (
-                kernel, dma, np.abs(got - ref).max())
+            assert (np.abs(got - ref) <= np.abs(ref) * 2.0 ** -10 + 1e-3).all(), "kernel=%d dma=%d flags=%d max err %g" % (
+                kernel, dma, flags, np.abs(got - ref).max())
     finally:
-        sr.set_option("kernel", 3)
+        sr.set_option("kernel", 4)
         sr.set_option("use_dma", 1)
+        sr.set_option("flow_flags", 0)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(192, 64, 20, 40), (64, 64, 33, 50), (192, 64, 70, 90)])
+def test_residual_epilogues_match_numpy(sr, cin, cout, h, w):
+    """The Eltwise / BinaryOp layers behind a Convolution in x4.param, fused into its epilogue: RDB conv5
+    (v = 0.2*conv + x, x4.param:17-18; x rides in the accumulator as an identity tap or is fetched: dbg 4096), every third
+    RDB (v = 0.2*v + rrdb_in, x4.param:47) and trunk_conv + global skip (x4.param:994-995).  One extra fp16 rounding of
+    the intermediate -> |d| <= 2^-9 |ref| + 2e-3.  num_cu = 8 gives every workgroup several blocks (ring wrap-around)."""
+    rng = np.random.default_rng(cin + h)
+    x = rng.standard_normal((cin, h, w)).astype(np.float16)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((cout, h, w)).astype(np.float16)
+    conv = oracle.conv3x3(x.astype(np.float32), wt, b, 0, 0.2)
+    x0, r = x[:cout].astype(np.float32), res.astype(np.float32)
+    forms = {"conv5": (0.2, True, None, 1.0, 0.2 * conv + x0), "conv5+rrdb": (0.2, True, res, 0.2, 0.2 * (0.2 * conv + x0) + r),
+             "trunk": (1.0, False, res, 1.0, conv + r)}
+    try:
+        for kernel, flags, dbg, ncu in ((4, 0, 0, 256), (4, 0, 4096, 256), (4, 1, 0, 256), (4, 0, 0, 8), (4, 1, 0, 8), (3, 0, 0, 256), (2, 0, 64, 256)):
+            for k, v in (("kernel", kernel), ("flow_flags", flags), ("dbg", dbg), ("num_cu", ncu)):
+                sr.set_option(k, v)
+            for name, (s1, own, rr, s2, ref) in forms.items():
+                got = sr.conv3x3_res(x, wt, b, s1, own_input_residual=own, res=rr, s2=s2).astype(np.float32)
+                assert (np.abs(got - ref) <= np.abs(ref) * 2.0 ** -9 + 2e-3).all(), (name, kernel, flags, dbg, ncu, np.abs(got - ref).max())
+    finally:
+        for k, v in (("kernel", 4), ("flow_flags", 0), ("dbg", 0), ("num_cu", 256)):
+            sr.set_option(k, v)
 
 
 # ---- the four shaders: bit exact --------------------------------------------------------------------
@@ -145,26 +176,30 @@ def test_network_tile_prequantise_error(sr, oracle_net, trunk_fp32):
 
 @pytest.mark.parametrize("w,h", [(28, 24), (64, 32), (45, 50)])
 def test_kernel_paths_agree(sr, w, h):
-    """The fast paths are restatements of the generic epilogue: in-stage epilogue of the ring kernel, LDS-row epilogue of
-    the 64-channel kernel, conv5's residual as an identity tap (ConvArgs::dbg switches them off).  Same arithmetic up to
+    """Every kernel generation and epilogue form is a restatement of the generic epilogue of the round-1 kernels:
+    conv3x3_flow on 16-channel planes (8x32 / 4x64 waves, deferred / inline epilogue, identity tap on / off), in-stage
+    epilogue of the ring kernel, LDS-row epilogue of the 64-channel kernel (ConvArgs::dbg switches).  Same arithmetic up to
     one fp16 rounding of 0.2*x5 -> every variant stays within 2e-3 of the generic path and +-1 after quantisation."""
     img = synth.make_image(17, w, h)
     x = (img.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)).astype(np.float16)
     q = lambda v: np.clip(np.floor(v * 255.0 + 0.5), 0, 255)
     try:
-        sr.set_option("dbg", 16)  # generic epilogue everywhere
+        sr.set_option("kernel", 3)
+        sr.set_option("dbg", 16)  # round-1 kernels with the generic epilogue everywhere
         ref = sr.net_forward(x).astype(np.float32)
-        for kernel, dbg in [(3, 0), (3, 4096), (3, 64), (2, 0), (1, 0)]:
+        for kernel, dbg, flags in [(4, 0, 0), (4, 0, 1), (4, 0, 2), (4, 4096, 0), (3, 0, 0), (3, 4096, 0), (3, 64, 0), (2, 0, 0), (1, 0, 0)]:
             sr.set_option("kernel", kernel)
             sr.set_option("dbg", dbg)
+            sr.set_option("flow_flags", flags)
             got = sr.net_forward(x).astype(np.float32)
-            assert np.isfinite(got).all(), (kernel, dbg)
+            assert np.isfinite(got).all(), (kernel, dbg, flags)
             d = np.abs(got - ref)
-            assert d.max() <= 2e-3, (kernel, dbg, d.max())
+            assert d.max() <= 2e-3, (kernel, dbg, flags, d.max())
             assert np.abs(q(got) - q(ref)).max() <= 1
     finally:
-        sr.set_option("kernel", 3)
+        sr.set_option("kernel", 4)
         sr.set_option("dbg", 0)
+        sr.set_option("flow_flags", 0)
 
 
 def test_oversized_tile_is_refused(sr):

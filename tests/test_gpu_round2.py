@@ -1,0 +1,274 @@
+"""GPU tests added in round 2 (run with -m gpu on the MI355X box): concurrency of rsr_process on one context, the
+workspace guard invariant, the BASELINE configurations that had no oracle check (C3, C5, the edge-tile classes of C2),
+a raw-fp32 x4.bin, pinned-memory I/O, blob validation, the bench's multi-rank control flow on one GPU.
+
+Everything goes through the C-ABI; the oracle is only the checker."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+import realsr_ncnn_vulkan_amd as R
+from realsr_ncnn_vulkan_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def paths(model_dir):
+    return os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin")
+
+
+@pytest.fixture(scope="module")
+def sr(paths):
+    s = R.RealSR(0)
+    s.load(*paths)
+    yield s
+    s.close()
+
+
+def padded_tile(img, x0, y0, tw, th, P=10):
+    """The padded network input of the tile whose un-padded origin is (x0, y0): reflect-101 at the image border
+    (realsr.cpp:613 copy_make_border type 2 == numpy 'reflect'), real neighbours elsewhere.  CHW float32 in [0,1]."""
+    big = np.pad(img, ((P, P), (P, P), (0, 0)), mode="reflect")
+    t = big[y0:y0 + th + 2 * P, x0:x0 + tw + 2 * P, :3]
+    return t.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+
+
+def quantise(ref, P=10):
+    """realsr.cpp:804,820-831: crop the halo, v*255 + 0.5, truncate, clamp."""
+    r = ref[:, 4 * P:-4 * P, 4 * P:-4 * P]
+    return np.clip((r * 255.0 + 0.5).astype(np.int32), 0, 255).transpose(1, 2, 0)
+
+
+def check_tile(out, img, net, x0, y0, tw, th):
+    ref8 = quantise(net.forward(padded_tile(img, x0, y0, tw, th)))
+    got = out[4 * y0:4 * (y0 + th), 4 * x0:4 * (x0 + tw)].astype(int)
+    d = np.abs(got - ref8)
+    assert d.max() <= 1, "tile at (%d,%d) %dx%d: max diff %d" % (x0, y0, tw, th, d.max())
+    return (d > 0).mean()
+
+
+# ---- concurrency -----------------------------------------------------------------------------------------------
+def test_concurrent_process_on_one_context(sr):
+    """The reference runs jobs_proc threads through ONE RealSR (main.cpp:811-828).  6 threads push images of 5 different
+    sizes (different plans, growing lane buffers, pageable and pinned destinations) through one context, 60 calls in all:
+    every result must be byte-identical to the serial result of the same image."""
+    sr.tilesize = 32
+    sizes = [(50, 43, 3), (70, 20, 3), (33, 64, 3), (37, 20, 4), (120, 90, 3)]
+    imgs = [synth.make_image(100 + i, w, h, c) for i, (w, h, c) in enumerate(sizes)]
+    sr._push_params()
+    want = [sr.process(im, push_params=False) for im in imgs]
+    errors = []
+
+    def worker(tid):
+        try:
+            pin = None
+            for it in range(10):
+                k = (tid * 3 + it) % len(imgs)
+                if (tid + it) % 3 == 0:  # every third call writes into pinned memory
+                    pin = R.PinnedArray(want[k].shape)
+                    got = sr.process(imgs[k], out=pin.array, push_params=False)
+                else:
+                    got = sr.process(imgs[k], push_params=False)
+                if not (got == want[k]).all():
+                    errors.append("thread %d iteration %d image %d: %d bytes differ" % (tid, it, k, int((got != want[k]).sum())))
+                if pin is not None:
+                    pin.free()
+                    pin = None
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (tid, e))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
+
+
+def test_concurrent_large_frames_share_the_workspace(sr):
+    """Two threads, full-HD-sized tiles (tile 200): the calls share one workspace and one compute stream; uploads and
+    downloads overlap the other call's kernels.  Results identical to the serial ones."""
+    sr.tilesize = 200
+    a, b = synth.make_image(31, 640, 420), synth.make_image(32, 500, 610)
+    sr._push_params()
+    wa, wb = sr.process(a, push_params=False), sr.process(b, push_params=False)
+    out, errs = {}, []
+
+    def run(name, img, want):
+        for _ in range(4):
+            got = sr.process(img, push_params=False)
+            if not (got == want).all():
+                errs.append(name)
+        out[name] = True
+
+    ts = [threading.Thread(target=run, args=("a", a, wa)), threading.Thread(target=run, args=("b", b, wb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs and len(out) == 2
+
+
+def test_pinned_buffers_equal_pageable(sr):
+    sr.tilesize = 32
+    img = synth.make_image(5, 61, 47)
+    want = sr.process(img)
+    pin_in, pin_out = R.PinnedArray(img.shape), R.PinnedArray(want.shape)
+    pin_in.array[:] = img
+    got = sr.process(pin_in.array, out=pin_out.array)
+    assert (got == want).all()
+    sr.set_option("chunk_mb", 1)  # pageable download in several chunks
+    try:
+        big = synth.make_image(6, 300, 260)
+        sr.tilesize = 200
+        w1 = sr.process(big)
+        p2 = R.PinnedArray(w1.shape)
+        assert (sr.process(big, out=p2.array) == w1).all()
+    finally:
+        sr.set_option("chunk_mb", 16)
+
+
+# ---- workspace guard invariant (every conv-input plane has a zero guard in front, whatever ran before) --------------------
+def test_guards_stay_zero_across_layout_and_slot_changes(paths):
+    """A large image lays the workspace out for many slots; a small-cap image re-lays it out with 2 slots; a third image
+    with the SAME slot capacity but more slots must not find stale activations where its guards are (conv zero padding
+    reads them).  Compared with a fresh context, byte for byte; both plane layouts (kernel 4: 16-channel, kernel 3: 32)."""
+    imgs = [synth.make_image(41, 150, 120), synth.make_image(42, 40, 20), synth.make_image(43, 100, 20)]
+    for kernel in (4, 3):
+        a = R.RealSR(0)
+        a.load(*paths)
+        a.tilesize = 32
+        a.set_option("kernel", kernel)
+        seq = [a.process(im) for im in imgs]
+        # and back to the first layout
+        again = a.process(imgs[0])
+        a.close()
+        for im, got in zip(imgs, seq):
+            f = R.RealSR(0)
+            f.load(*paths)
+            f.tilesize = 32
+            f.set_option("kernel", kernel)
+            want = f.process(im)
+            f.close()
+            assert (got == want).all(), "kernel %d: image %s differs from a fresh context" % (kernel, im.shape)
+        assert (again == seq[0]).all()
+
+
+# ---- BASELINE configs that had no oracle check ----------------------------------------------------------------------------
+def test_c2_edge_tile_classes_against_oracle(sr, oracle_net):
+    """C2 (1920x1080, tile 200) has four tile shapes: 220x220, 220x100 (last tile row), 140x220 (last column), 140x100
+    (corner).  One tile of each edge class against the oracle network, +-1 uint8."""
+    sr.tilesize = 200
+    img = synth.make_image(1235, 1920, 1080)
+    out = sr.process(img)
+    check_tile(out, img, oracle_net, 600, 1000, 200, 80)    # 220 x 100
+    check_tile(out, img, oracle_net, 1800, 400, 120, 200)   # 140 x 220
+    check_tile(out, img, oracle_net, 1800, 1000, 120, 80)   # 140 x 100
+
+
+def test_c3_tiles_against_oracle_and_batching(sr, oracle_net):
+    """C3 (3840x2160, tile 400): the default 64 GiB workspace budget splits the 60 tiles into 2 batches.  One interior
+    420x420 tile and the 260x180 corner slot against the oracle; the whole frame again with a 200 GiB budget (1 batch)
+    must be byte-identical (batches are an implementation detail)."""
+    sr.tilesize = 400
+    img = synth.make_image(1236, 3840, 2160)
+    out = sr.process(img)
+    assert out.shape == (8640, 15360, 3)
+    check_tile(out, img, oracle_net, 1200, 800, 400, 400)   # interior 420 x 420
+    check_tile(out, img, oracle_net, 3600, 2000, 240, 160)  # corner 260 x 180
+    sr.set_option("max_workspace_mb", 200 * 1024)
+    try:
+        one = sr.process(img)
+    finally:
+        sr.set_option("max_workspace_mb", 65536)
+    assert (one == out).all()
+    assert (sr.process(img) == out).all()  # determinism
+
+
+def test_c5_tta_at_tile_200_against_oracle(paths, oracle_net):
+    """C5's code path: TTA x8 at tile 200 on an image whose grid has all four tile shapes (non-square edge tiles: the 4+4
+    transposed-shape slots of engine.cpp / realsr.cpp:251-258).  Whole image against the oracle's TTA path, +-1 uint8."""
+    s = R.RealSR(0, tta_mode=True)
+    s.load(*paths)
+    s.tilesize = 200
+    img = synth.make_image(1239, 260, 230)
+    got = s.process(img)
+    s.close()
+    ref = oracle_net.process(img, 200, tta=True)
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert d.max() <= 1
+    assert (d > 0).mean() < 0.15
+
+
+def test_raw_fp32_bin_with_unrepresentable_weights(tmp_path):
+    """A raw-fp32 x4.bin (tag 0) whose weights are NOT fp16-representable: the packer rounds them to
+    fp16 (what ncnn's Vulkan fp16-storage path does), the oracle keeps fp32.  Stated tolerance: +-1 uint8 on >= 99.9 % of
+    the bytes, never more than 2 (weight rounding adds ~2^-11 relative error per product)."""
+    d = synth.make_model_dir(str(tmp_path), "models-raw32", 44, encoding="fp32", round_fp16=False)
+    pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+    assert R.model_info(pp, bp)["bin_encoding"] == 0
+    net = oracle.OracleNet(pp, bp)
+    w0 = net.conv(5)["weight"]
+    assert (w0.astype(np.float16).astype(np.float32) != w0).mean() > 0.5  # really not fp16 values
+    s = R.RealSR(0)
+    s.load(pp, bp)
+    s.tilesize = 64
+    img = synth.make_image(77, 90, 70)
+    got = s.process(img)
+    # pre-quantise error of one tile, for the record
+    x = padded_tile(img, 0, 0, 64, 64)
+    e = np.abs(s.net_forward(x.astype(np.float16)).astype(np.float32) - net.forward(x.astype(np.float16).astype(np.float32)))
+    print("raw-fp32 weights: pre-quantise max %.3e p99.9 %.3e" % (e.max(), np.quantile(e, 0.999)))
+    s.close()
+    ref = net.process(img, 64)
+    dd = np.abs(got.astype(int) - ref.astype(int))
+    assert dd.max() <= 2 and (dd > 1).mean() <= 1e-3
+    assert e.max() <= 6e-3
+
+
+# ---- blob validation (a failed load must leave the loaded model intact) ------------------------------------------------------
+def test_corrupt_blob_is_refused_and_state_survives(paths, sr):
+    sr.tilesize = 32
+    img = synth.make_image(8, 40, 30)
+    want = sr.process(img)
+    blob = R.model_pack(*paths, with_w32=False)
+    rec = np.dtype([("cin", "<u4"), ("cout", "<u4"), ("act", "<u4"), ("nplanes", "<u4"), ("nt", "<u4"),
+                    ("slope", "<f4"), ("w_off", "<u8"), ("b_off", "<u8"), ("w16_off", "<u8")])
+    for field, value in (("w16_off", blob.size - 256), ("cin", 96), ("nt", 2), ("b_off", blob.size + 4096)):
+        bad = blob.copy()
+        table = bad[24:24 + 351 * 48].view(rec)
+        table[7][field] = value
+        with pytest.raises(R.RealSRError) as e:
+            sr.load_packed(bad)
+        assert e.value.code == R.RSR_E_FORMAT, field
+        assert (sr.process(img) == want).all(), "a refused blob must not disturb the loaded model"
+    # the slim blob itself loads and gives the same bytes; the round-1 kernels refuse it (no 32-channel images)
+    s2 = R.RealSR(0)
+    s2.load_packed(blob)
+    s2.tilesize = 32
+    assert (s2.process(img) == want).all()
+    s2.set_option("kernel", 3)
+    with pytest.raises(R.RealSRError):
+        s2.process(img)
+    s2.close()
+
+
+# ---- bench.py's multi-rank control flow, executed on ONE gpu (the driver's 8-GPU run is the first real one otherwise) ----------
+def test_bench_multirank_control_flow_on_one_gpu(tmp_path):
+    env = dict(os.environ, RSR_BENCH_SAME_GPU="1", RSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "weak"

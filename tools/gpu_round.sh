@@ -1,16 +1,24 @@
 #!/bin/bash
-# One GPU-box session: bench JSON, rocprofv3 kernel-trace stats, PMC traffic passes.  Usage: tools/gpu_round.sh <tag>
-TAG=${1:-r01}
+# One GPU-box session: bench JSON, rocprofv3 kernel-trace stats, PMC passes (HBM traffic + MFMA / LDS / clock counters).
+# Usage: tools/gpu_round.sh <tag>     -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc_traffic.txt,pmc_counters.txt}
+# Copy the summaries you want judged into profiles/ (tracked).
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1; echo "trace rc=$?"
-for SET in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pmc_$SET -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $OUT/pmc_$SET.log 2>&1; echo "pmc $SET rc=$?"
+timeout 900 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline --no-host > $OUT/trace.log 2>&1; echo "trace rc=$?"
+BA="--steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host"
+i=0
+# separate --pmc passes, kernel-trace only (no other trace domain): FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2; SQ has 8 slots
+for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pmc$i -- python $R/bench.py $BA > $OUT/pmc$i.log 2>&1; echo "pmc pass $i ($SET) rc=$?"
 done
-python $R/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_summary.txt 2>&1
+python $R/tools/pmc_summary.py --traffic $OUT/pmc1 $OUT/pmc2 > $OUT/pmc_traffic.txt 2>&1
+python $R/tools/pmc_summary.py $OUT/pmc3 $OUT/pmc4 > $OUT/pmc_counters.txt 2>&1
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
-find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete
-ls -la $OUT
+find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
+ls -la $OUT; cat $OUT/pmc_traffic.txt | head -30

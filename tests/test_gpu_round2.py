@@ -242,10 +242,10 @@ def test_corrupt_blob_is_refused_and_state_survives(paths, sr):
     blob = R.model_pack(*paths, with_w32=False)
     rec = np.dtype([("cin", "<u4"), ("cout", "<u4"), ("act", "<u4"), ("nplanes", "<u4"), ("nt", "<u4"),
                     ("slope", "<f4"), ("w_off", "<u8"), ("b_off", "<u8"), ("w16_off", "<u8")])
-    for field, value in (("w16_off", blob.size - 256), ("cin", 96), ("nt", 2), ("b_off", blob.size + 4096)):
+    for field, value in (("w16_off", blob.size - 256), ("cin", 128), ("nt", 2), ("b_off", blob.size + 4096)):
         bad = blob.copy()
         table = bad[24:24 + 351 * 48].view(rec)
-        table[7][field] = value
+        table[field][7] = value
         with pytest.raises(R.RealSRError) as e:
             sr.load_packed(bad)
         assert e.value.code == R.RSR_E_FORMAT, field

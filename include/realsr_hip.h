@@ -103,6 +103,24 @@ int rsr_model_pack_ex(const char* parampath, const char* modelpath, void* dst, s
  * pointer on this context's GPU (is_device=1). */
 int rsr_load_packed(rsr_ctx* ctx, const void* blob, size_t bytes, int is_device);
 
+/* ---- several GPUs of one node ------------------------------------------------ */
+/* What main.cpp:778-791 does per GPU (construct, load), for n GPUs at once: the model is parsed and packed once, uploaded to
+ * gpuids[0] and broadcast to the other devices with ONE RCCL collective over xGMI (librccl is dlopen'ed; when it is not
+ * available the blob is uploaded to every device from the host instead -- rsr_group_transport() tells which).  out[0..n-1]
+ * receive the contexts (all NULL on failure).  Images are then dealt to the contexts by the caller's work queue
+ * (main.cpp:811-828), or ONE large image is split with rsr_process_group. */
+int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, const char* parampath, const char* modelpath);
+const char* rsr_group_transport(void); /* "rccl" | "host ..." for the calling thread's last rsr_create_group */
+
+/* RealSR::process restricted to the tile rows [tile_row_begin, tile_row_end) of the image's tile grid (tiles are independent:
+ * realsr.cpp:377-380,458-459).  `in` is the whole image, `out` the whole (4w x 4h x c) output; only the output rows of those
+ * tiles are written.  Disjoint row ranges may run concurrently on different contexts into the same `out`. */
+int rsr_process_rows(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out, int tile_row_begin, int tile_row_end);
+
+/* One image over n contexts (normally one per GPU): the tile rows are split evenly, every context runs its share on its own
+ * thread, the call returns when `out` is complete.  All contexts must carry the same parameters. */
+int rsr_process_group(rsr_ctx* const* ctx, int n, const uint8_t* in, int w, int h, int c, uint8_t* out);
+
 /* Host-only model introspection (no GPU): conv count, weight/bias counts and the .bin encoding
  * (1 = fp16-tagged, 0 = raw fp32, 2 = mixed/table).  Any pointer may be NULL. */
 int rsr_model_info(const char* parampath, const char* modelpath, int* n_layers, int* n_convs,

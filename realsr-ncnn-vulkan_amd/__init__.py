@@ -24,7 +24,8 @@ EXPORTS = [
     "rsr_model_pack", "rsr_load_packed", "rsr_model_info", "rsr_preproc", "rsr_preproc_tta", "rsr_postproc",
     "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times", "rsr_get_trace",
     "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_model_pack_ex", "rsr_host_alloc", "rsr_host_free",
-    "rsr_set_progress_callback", "rsr_conv3x3_res",
+    "rsr_set_progress_callback", "rsr_conv3x3_res", "rsr_create_group", "rsr_group_transport", "rsr_process_rows",
+    "rsr_process_group",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -98,6 +99,10 @@ def lib():
     L.rsr_net_forward.argtypes = [vp, vp, ip, ip, vp]
     L.rsr_conv3x3.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp]
     L.rsr_conv3x3_res.argtypes = [vp, vp, ip, ip, ip, vp, vp, ip, C.c_float, ip, vp, C.c_float, vp]
+    L.rsr_create_group.argtypes = [C.POINTER(vp), C.POINTER(ip), ip, ip, cp, cp]
+    L.rsr_group_transport.restype = cp
+    L.rsr_process_rows.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip]
+    L.rsr_process_group.argtypes = [C.POINTER(vp), ip, vp, ip, ip, ip, vp]
     L.rsr_set_profiling.argtypes = [vp, ip]
     L.rsr_get_profile.argtypes = [vp, C.POINTER(Profile), ip]
     L.rsr_get_conv_times.argtypes = [vp, C.POINTER(C.c_double), ip, ip]
@@ -171,12 +176,15 @@ class RealSR:
     prepadding; process(in HWC uint8) -> out HWC uint8.
     """
 
-    def __init__(self, gpuid, tta_mode=False, num_threads=1):
+    def __init__(self, gpuid, tta_mode=False, num_threads=1, _adopt=None):
         self._L = lib()
-        h = C.c_void_p()
-        rc = self._L.rsr_create(C.byref(h), int(gpuid), int(bool(tta_mode)), int(num_threads))
-        if rc != 0:
-            raise RealSRError(rc, self._L.rsr_last_error(None).decode())
+        if _adopt is not None:
+            h = _adopt
+        else:
+            h = C.c_void_p()
+            rc = self._L.rsr_create(C.byref(h), int(gpuid), int(bool(tta_mode)), int(num_threads))
+            if rc != 0:
+                raise RealSRError(rc, self._L.rsr_last_error(None).decode())
         self._h = h
         self.scale, self.tilesize, self.prepadding = 4, 200, 10
         self.tta_mode = bool(tta_mode)
@@ -231,6 +239,13 @@ class RealSR:
         self._push_params()
         self._ck(self._L.rsr_process_device(self._h, C.c_void_p(int(d_in)), w, h, c, C.c_void_p(int(d_out)),
                                             C.c_void_p(int(stream)) if stream else None))
+
+    def process_rows(self, img, out, row0, row1):
+        """Tile rows [row0, row1) of img's tile grid into the full-size `out` (see rsr_process_rows)."""
+        h, w, c = img.shape
+        self._push_params()
+        self._ck(self._L.rsr_process_rows(self._h, _p(img), w, h, c, _p(out), int(row0), int(row1)))
+        return out
 
     def net_forward(self, x):
         """x: float16 planar (3,h,w) -> float16 (3,4h,4w)."""
@@ -321,6 +336,34 @@ class RealSR:
         p = Profile()
         self._ck(self._L.rsr_get_profile(self._h, C.byref(p), int(bool(reset))))
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+def create_group(gpuids, parampath, modelpath, tta_mode=False):
+    """rsr_create_group: one context per GPU, the model packed once and broadcast (RCCL).  Returns (list of RealSR, transport)."""
+    L = lib()
+    n = len(gpuids)
+    hs = (C.c_void_p * n)()
+    ids = (C.c_int * n)(*[int(g) for g in gpuids])
+    rc = L.rsr_create_group(hs, ids, n, int(bool(tta_mode)), str(parampath).encode(), str(modelpath).encode())
+    if rc != 0:
+        raise RealSRError(rc, L.rsr_last_error(None).decode())
+    srs = [RealSR(int(g), tta_mode, _adopt=C.c_void_p(hs[i])) for i, g in enumerate(gpuids)]
+    return srs, L.rsr_group_transport().decode()
+
+
+def process_group(srs, img):
+    """rsr_process_group: ONE image, its tile rows split over the contexts."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, c = img.shape
+    for s in srs:
+        s._push_params()
+    out = np.empty((h * 4, w * 4, c), dtype=np.uint8)
+    hs = (C.c_void_p * len(srs))(*[s._h for s in srs])
+    rc = L.rsr_process_group(hs, len(srs), _p(img), w, h, c, _p(out))
+    if rc != 0:
+        raise RealSRError(rc, L.rsr_last_error(None).decode())
+    return out
 
 
 # ---- tile sharding for multi-GPU runs (SURVEY.md 8(e)): pure host logic, shared by bench + tests ----

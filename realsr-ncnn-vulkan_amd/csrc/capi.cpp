@@ -8,7 +8,7 @@
 
 using namespace rsr;
 
-struct rsr_ctx
+struct rsr_ctx // the same definition lives in group.cpp
 {
     Engine e;
 };

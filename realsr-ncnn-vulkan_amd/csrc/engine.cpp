@@ -247,11 +247,11 @@ static hipError_t upload_batch(Plan::Batch& b, char*& d)
 static constexpr long long kBytesPerPx = 64 + 128 + 3 * 384 + 256 + 256 + 512 + 2048 + 2048 + 96;
 static constexpr size_t kMaxPlans = 8;
 
-int Engine::get_plan(int w, int h, int c, Plan*& out)
+int Engine::get_plan(int w, int h, int c, int row0, int row1, Plan*& out)
 {
     for (auto it = plans.begin(); it != plans.end(); ++it)
         if (it->w == w && it->h == h && it->c == c && it->T == tilesize && it->P == prepadding && it->tta == tta &&
-            it->budget_mb == max_workspace_mb)
+            it->row0 == row0 && it->row1 == row1 && it->budget_mb == max_workspace_mb)
         {
             plans.splice(plans.begin(), plans, it); // most recently used first
             out = &plans.front();
@@ -263,7 +263,8 @@ int Engine::get_plan(int w, int h, int c, Plan*& out)
     std::vector<BaseTile> all;
     long long cap = 0;
     int mtw = 0, mth = 0;
-    for (int yi = 0; yi < ytiles; yi++)
+    if (row0 < 0 || row1 > ytiles || row0 >= row1) return fail(RSR_E_ARG, "tile row range outside the image");
+    for (int yi = row0; yi < row1; yi++)
         for (int xi = 0; xi < xtiles; xi++)
         {
             const int twn = std::min((xi + 1) * T, w) - xi * T;
@@ -302,6 +303,7 @@ int Engine::get_plan(int w, int h, int c, Plan*& out)
 
     Plan plan;
     plan.w = w; plan.h = h; plan.c = c; plan.T = T; plan.P = P; plan.tta = tta;
+    plan.row0 = row0; plan.row1 = row1;
     plan.budget_mb = max_workspace_mb;
     plan.cap_px = cap;
     plan.max_tw = mtw;
@@ -619,10 +621,11 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st)
 
 // ---- process ----------------------------------------------------------------------------------
 // enqueue preproc -> network -> postproc for every tile batch of one image on `st` (mu held)
-int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st)
+int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0, int row1)
 {
     Plan* planp = nullptr;
-    int rc = get_plan(w, h, c, planp);
+    if (row1 < 0) row1 = (h + tilesize - 1) / tilesize;
+    int rc = get_plan(w, h, c, row0, row1, planp);
     if (rc != RSR_OK) return rc;
     const Plan& plan = *planp;
     rc = ensure_workspace(plan.slots_per_batch, plan.cap_px, st);
@@ -781,10 +784,10 @@ static int ensure_pinned(void*& p, size_t& have, size_t need)
 // stream (ordered by events), download on the copy stream again.  Pinned caller memory (rsr_host_alloc, hipHostMalloc,
 // hipHostRegister) is copied directly; pageable memory goes through the lane's pinned staging, the download in chunks so
 // that the CPU copy of chunk i overlaps the PCIe transfer of chunk i+1.
-int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out)
+int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, int row0, int row1)
 {
     if (!in || !out || w < 1 || h < 1 || (c != 3 && c != 4)) return fail(RSR_E_ARG, "bad image arguments");
-    const size_t nin = size_t(w) * h * c, nout = nin * size_t(scale) * scale;
+    const size_t nin = size_t(w) * h * c, nout_full = nin * size_t(scale) * scale;
     Lane* L = acquire_lane();
     struct Release
     {
@@ -800,7 +803,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out)
     }
     int rc;
     if ((rc = ensure(L->d_in, nin)) != RSR_OK) return rc;  // lane-private: nothing else can be using the old allocation
-    if ((rc = ensure(L->d_out, nout)) != RSR_OK) return rc;
+    if ((rc = ensure(L->d_out, nout_full)) != RSR_OK) return rc;
 
     // ---- upload ----
     const void* src = in;
@@ -814,12 +817,24 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out)
     HIP_TRY(hipEventRecord(L->ev_in, L->copy));
 
     // ---- network ----
+    size_t out_off = 0, nout = nout_full;
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!loaded) return fail(RSR_E_STATE, "process before load");
         if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
         HIP_TRY(hipStreamWaitEvent(stream, L->ev_in, 0));
-        rc = enqueue_image(L->d_in.p, w, h, c, L->d_out.p, stream);
+        const int ytiles = (h + tilesize - 1) / tilesize;
+        if (row1 < 0) row1 = ytiles;
+        if (row0 < 0 || row1 > ytiles || row0 >= row1)
+        {
+            (void)hipStreamSynchronize(L->copy);
+            return fail(RSR_E_ARG, "tile row range outside the image");
+        }
+        // output rows of the tile rows [row0, row1): a contiguous byte range of the HWC image
+        const size_t rowbytes = size_t(w) * scale * c;
+        out_off = size_t(row0) * tilesize * scale * rowbytes;
+        nout = size_t(std::min(row1 * tilesize, h) - row0 * tilesize) * scale * rowbytes;
+        rc = enqueue_image(L->d_in.p, w, h, c, L->d_out.p, stream, row0, row1);
         if (rc != RSR_OK)
         {
             (void)hipStreamSynchronize(L->copy);
@@ -830,9 +845,10 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out)
     HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_done, 0));
 
     // ---- download ----
+    out += out_off;
     if (is_pinned_host(out))
     {
-        HIP_TRY(hipMemcpyAsync(out, L->d_out.p, nout, hipMemcpyDeviceToHost, L->copy));
+        HIP_TRY(hipMemcpyAsync(out, static_cast<const char*>(L->d_out.p) + out_off, nout, hipMemcpyDeviceToHost, L->copy));
         HIP_TRY(hipStreamSynchronize(L->copy));
         return RSR_OK;
     }
@@ -840,7 +856,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out)
     if ((rc = ensure_pinned(L->h_out, L->h_out_bytes, 2 * std::min(CH, nout))) != RSR_OK) return rc;
     const size_t half = L->h_out_bytes / 2;
     const size_t nchunks = (nout + half - 1) / half;
-    const char* dsrc = static_cast<const char*>(L->d_out.p);
+    const char* dsrc = static_cast<const char*>(L->d_out.p) + out_off;
     for (size_t i = 0; i <= nchunks; i++)
     {
         if (i < nchunks)

@@ -38,6 +38,7 @@ struct DevBuf
 struct Plan
 {
     int w = 0, h = 0, c = 0, T = 0, P = 0, tta = 0;
+    int row0 = 0, row1 = 0; // tile rows [row0, row1) of the image this plan covers (multi-GPU tile sharding)
     long long budget_mb = 0;
     long long cap_px = 0; // slot capacity in LR pixels
     int max_tw = 0, max_th = 0;
@@ -139,7 +140,9 @@ struct Engine
     // d_in/d_out on this device.  user_stream == nullptr: returns when the output is complete (sync) or enqueued (!sync);
     // otherwise ordered after / before the work of user_stream, asynchronous.
     int process_device(const void* d_in, int w, int h, int c, void* d_out, hipStream_t user_stream, bool sync);
-    int process_host(const uint8_t* in, int w, int h, int c, uint8_t* out);
+    // row0/row1: tile rows [row0, row1) only (row1 < 0: all); `out` is always the full (4w x 4h x c) image, only the rows of
+    // those tiles are written
+    int process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, int row0 = 0, int row1 = -1);
     int net_forward(const uint16_t* in, int w, int h, uint16_t* out);
     // out = act(conv + b); with s1 != 0: v = s1*(conv + b) [+ in[0:cout] when own_res] [, v = s2*v + res when res]
     int conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout, int lrelu,
@@ -150,11 +153,11 @@ struct Engine
     int eff_kernel() const { return (kernel_version >= 4 && trunk_fp32) ? 3 : kernel_version; }
     int ensure(DevBuf& b, size_t bytes);
     int ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool layout_changed, bool zero_all, hipStream_t st);
-    int get_plan(int w, int h, int c, Plan*& out);
+    int get_plan(int w, int h, int c, int row0, int row1, Plan*& out);
     int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
     int run_network(const Plan::Batch& b, hipStream_t st);
     int launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st);
-    int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st);
+    int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0 = 0, int row1 = -1);
     void mark_begin(hipStream_t st);
     void mark(int cls, double flops, double bytes, hipStream_t st, int conv_index = -1);
     void collect_profile(hipStream_t st);

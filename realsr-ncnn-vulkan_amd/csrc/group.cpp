@@ -1,0 +1,235 @@
+// group.cpp -- several GPUs of one node behind the C-ABI: rsr_create_group / rsr_process_rows / rsr_process_group.
+//
+// The reference creates one RealSR per GPU and lets every one of them re-read x4.bin (main.cpp:778-791).  Here the model is
+// parsed, validated and packed ONCE; the blob is uploaded to the first GPU and reaches the others through ONE RCCL
+// broadcast over xGMI (the only collective of this workload -- tiles and images are independent).
+// RCCL is resolved with dlopen at run time: the library has no link-time dependency on it, a process that already
+// carries an RCCL (PyTorch) shares that copy, and a single-GPU user never loads it.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine.h"
+
+using namespace rsr;
+
+struct rsr_ctx
+{
+    Engine e;
+};
+
+namespace {
+
+// the six entry points we use, as declared by rccl/rccl.h (ncclResult_t = int, ncclComm_t = opaque pointer,
+// ncclDataType_t ncclUint8 = 1)
+struct Rccl
+{
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void* send, void* recv, size_t count, int dtype, int root, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+
+    bool open(std::string& why)
+    {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+        if (!lib)
+        {
+            why = std::string("dlopen(librccl): ") + dlerror();
+            return false;
+        }
+        auto sym = [&](const char* n) { return dlsym(lib, n); };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast)
+        {
+            why = "librccl lacks a required symbol";
+            return false;
+        }
+        return true;
+    }
+    std::string err(int rc) const { return GetErrorString ? GetErrorString(rc) : ("nccl error " + std::to_string(rc)); }
+};
+
+thread_local std::string g_transport = "none";
+
+// dst[i] (device i, `bytes` each) <- src on device gpuids[0], one broadcast.  false + why on any failure.
+bool rccl_broadcast(const int* gpuids, int n, const void* src, void* const* dst, size_t bytes, std::string& why)
+{
+    Rccl r;
+    if (!r.open(why)) return false;
+    std::vector<void*> comms(size_t(n), nullptr);
+    int rc = r.CommInitAll(comms.data(), n, gpuids);
+    if (rc != 0)
+    {
+        why = "ncclCommInitAll: " + r.err(rc);
+        return false;
+    }
+    std::vector<hipStream_t> streams(size_t(n), nullptr);
+    bool ok = true;
+    for (int i = 0; i < n && ok; i++)
+        ok = hipSetDevice(gpuids[i]) == hipSuccess && hipStreamCreateWithFlags(&streams[size_t(i)], hipStreamNonBlocking) == hipSuccess;
+    if (ok)
+    {
+        rc = r.GroupStart();
+        for (int i = 0; i < n && rc == 0; i++)
+        {
+            (void)hipSetDevice(gpuids[i]);
+            rc = r.Broadcast(i == 0 ? src : dst[i], dst[i], bytes, /*ncclUint8*/ 1, /*root*/ 0, comms[size_t(i)], streams[size_t(i)]);
+        }
+        const int rc2 = r.GroupEnd();
+        if (rc == 0) rc = rc2;
+        if (rc != 0)
+        {
+            why = "ncclBroadcast: " + r.err(rc);
+            ok = false;
+        }
+    }
+    else
+        why = "stream creation failed";
+    for (int i = 0; i < n; i++)
+        if (streams[size_t(i)])
+        {
+            (void)hipSetDevice(gpuids[i]);
+            if (hipStreamSynchronize(streams[size_t(i)]) != hipSuccess && ok)
+            {
+                ok = false;
+                why = "broadcast stream failed";
+            }
+            (void)hipStreamDestroy(streams[size_t(i)]);
+        }
+    for (void* c : comms)
+        if (c) (void)r.CommDestroy(c);
+    return ok;
+}
+
+} // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, const char* parampath, const char* modelpath)
+{
+    if (!out || !gpuids || n < 1 || !parampath || !modelpath) return Engine::fail(RSR_E_ARG, "bad arguments");
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (gpuids[i] == gpuids[j]) return Engine::fail(RSR_E_ARG, "duplicate gpu id in group");
+    // parse + validate + pack once on the host (the slim blob: no round-1 weight images)
+    Model m;
+    std::string err;
+    int rc = load_model(parampath, modelpath, m, err);
+    if (rc != RSR_OK) return Engine::fail(rc, err);
+    std::vector<unsigned char> blob(packed_size(m, false));
+    rc = pack_model(m, blob.data(), blob.size(), err, false);
+    if (rc != RSR_OK) return Engine::fail(rc, err);
+    auto destroy_all = [&]() {
+        for (int i = 0; i < n; i++)
+        {
+            delete out[i];
+            out[i] = nullptr;
+        }
+    };
+    for (int i = 0; i < n; i++)
+    {
+        rc = rsr_create(&out[i], gpuids[i], tta_mode, 1);
+        if (rc != RSR_OK)
+        {
+            destroy_all();
+            return rc;
+        }
+    }
+    g_transport = "host";
+    bool done = false;
+    if (n > 1)
+    {
+        // device staging buffers: blob on GPU 0, receive buffers on the others
+        std::vector<void*> dbuf(size_t(n), nullptr);
+        bool ok = true;
+        for (int i = 0; i < n && ok; i++)
+            ok = hipSetDevice(gpuids[i]) == hipSuccess && hipMalloc(&dbuf[size_t(i)], blob.size()) == hipSuccess;
+        ok = ok && hipSetDevice(gpuids[0]) == hipSuccess && hipMemcpy(dbuf[0], blob.data(), blob.size(), hipMemcpyHostToDevice) == hipSuccess;
+        std::string why = "device staging failed";
+        if (ok && rccl_broadcast(gpuids, n, dbuf[0], dbuf.data(), blob.size(), why))
+        {
+            done = true;
+            for (int i = 0; i < n && rc == RSR_OK; i++)
+            {
+                std::lock_guard<std::mutex> lk(out[i]->e.mu);
+                rc = out[i]->e.load_blob_device(dbuf[size_t(i)], blob.size());
+            }
+            g_transport = "rccl";
+        }
+        else
+        {
+            (void)hipGetLastError();
+            g_transport = "host (rccl unavailable: " + why + ")";
+        }
+        for (int i = 0; i < n; i++)
+            if (dbuf[size_t(i)])
+            {
+                (void)hipSetDevice(gpuids[i]);
+                (void)hipFree(dbuf[size_t(i)]);
+            }
+    }
+    if (!done)
+        for (int i = 0; i < n && rc == RSR_OK; i++)
+        {
+            std::lock_guard<std::mutex> lk(out[i]->e.mu);
+            rc = out[i]->e.load_blob_host(blob.data(), blob.size());
+        }
+    if (rc != RSR_OK)
+    {
+        const std::string keep = rsr::last_error();
+        destroy_all();
+        return Engine::fail(rc, keep);
+    }
+    return RSR_OK;
+}
+
+const char* rsr_group_transport(void) { return g_transport.c_str(); }
+
+int rsr_process_rows(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out, int tile_row_begin, int tile_row_end)
+{
+    if (!ctx) return RSR_E_ARG;
+    return ctx->e.process_host(in, w, h, c, out, tile_row_begin, tile_row_end);
+}
+
+int rsr_process_group(rsr_ctx* const* ctx, int n, const uint8_t* in, int w, int h, int c, uint8_t* out)
+{
+    if (!ctx || n < 1 || !in || !out || w < 1 || h < 1) return Engine::fail(RSR_E_ARG, "bad arguments");
+    for (int i = 0; i < n; i++)
+        if (!ctx[i]) return Engine::fail(RSR_E_ARG, "null context in group");
+    const int T = ctx[0]->e.tilesize;
+    const int ytiles = (h + T - 1) / T;
+    const int parts = std::min(n, ytiles);
+    if (parts == 1) return ctx[0]->e.process_host(in, w, h, c, out);
+    std::vector<int> rcs(size_t(parts), RSR_OK);
+    std::vector<std::string> errs{size_t(parts)};
+    std::vector<std::thread> th;
+    for (int i = 0; i < parts; i++)
+        th.emplace_back([&, i] {
+            const int r0 = int((long long)ytiles * i / parts), r1 = int((long long)ytiles * (i + 1) / parts);
+            rcs[size_t(i)] = ctx[i]->e.process_host(in, w, h, c, out, r0, r1);
+            if (rcs[size_t(i)] != RSR_OK) errs[size_t(i)] = rsr::last_error();
+        });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < parts; i++)
+        if (rcs[size_t(i)] != RSR_OK) return Engine::fail(rcs[size_t(i)], "gpu share " + std::to_string(i) + ": " + errs[size_t(i)]);
+    return RSR_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop

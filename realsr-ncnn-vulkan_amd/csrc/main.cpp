@@ -3,9 +3,12 @@
 // dir, :748-775 tile policy, :117-177/:190-416/:793-867 load -> proc -> save pipeline), re-implemented on
 // std::thread + the C-ABI engine.  SURVEY.md 8(f-1).  Differences, all deliberate:
 //   * -g ids are HIP devices; "-g -1" (ncnn CPU path) is refused: this build has no CPU fallback;
-//   * the model is parsed + packed ONCE and the blob is handed to every GPU context (the reference re-reads
-//     x4.bin per GPU, main.cpp:784-786);
-//   * codecs: png + binary pnm in, png out (image_io.h); jpg/webp need libraries this toolchain lacks;
+//   * the model is parsed + packed ONCE and reaches the GPUs of "-g 0,1,.." by one RCCL broadcast (rsr_create_group; the
+//     reference re-reads x4.bin per GPU, main.cpp:784-786);
+//   * a single input image with several GPUs is split by tile rows over all of them (rsr_process_group); directories are
+//     dealt image by image from the shared queue exactly like the reference (main.cpp:811-828);
+//   * codecs: stb_image / stb_image_write as in the reference (jpg, png, ... in; png, jpg out) + binary pnm; webp needs
+//     libwebp, which this toolchain lacks;
 //   * "-j l:p:s" accepts a single proc count for several GPUs (the reference insists on one per GPU).
 #include <dirent.h>
 #include <sys/stat.h>
@@ -31,15 +34,15 @@ static void print_usage()
     fprintf(stderr, "Usage: realsr-hip -i infile -o outfile [options]...\n\n");
     fprintf(stderr, "  -h                   show this help\n");
     fprintf(stderr, "  -v                   verbose output\n");
-    fprintf(stderr, "  -i input-path        input image path (png/pnm) or directory\n");
-    fprintf(stderr, "  -o output-path       output image path (png) or directory\n");
+    fprintf(stderr, "  -i input-path        input image path (jpg/png/pnm) or directory\n");
+    fprintf(stderr, "  -o output-path       output image path (jpg/png) or directory\n");
     fprintf(stderr, "  -s scale             upscale ratio (4, default=4)\n");
     fprintf(stderr, "  -t tile-size         tile size (>=32/0=auto, default=0) can be 0,0,0 for multi-gpu\n");
     fprintf(stderr, "  -m model-path        realsr model path (default=models-DF2K_JPEG)\n");
     fprintf(stderr, "  -g gpu-id            gpu device to use (default=0) can be 0,1,2 for multi-gpu\n");
     fprintf(stderr, "  -j load:proc:save    thread count for load/proc/save (default=1:2:2) can be 1:2,2,2:2 for multi-gpu\n");
     fprintf(stderr, "  -x                   enable tta mode\n");
-    fprintf(stderr, "  -f format            output image format (png, default=ext/png)\n");
+    fprintf(stderr, "  -f format            output image format (jpg/png, default=ext/png)\n");
 }
 
 static std::vector<int> parse_int_list(const char* s)
@@ -241,9 +244,9 @@ int main(int argc, char** argv)
         fprintf(stderr, "invalid format argument\n");
         return -1;
     }
-    if (format != "png")
+    if (format == "webp")
     {
-        fprintf(stderr, "output format %s is not built in (png only: no libjpeg/libwebp headers in this toolchain)\n", format.c_str());
+        fprintf(stderr, "output format webp is not built in (no libwebp in this toolchain)\n");
         return -1;
     }
 
@@ -299,37 +302,28 @@ int main(int argc, char** argv)
     for (int& t : tilesize)
         if (t == 0) t = 200; // reference policy: heap budget > 1900 MB -> 200 (main.cpp:766-767); an MI355X always qualifies
 
-    // parse + validate + pack once on the host
-    size_t need = 0;
-    if (rsr_model_pack(parampath.c_str(), modelpath.c_str(), nullptr, 0, &need) != RSR_OK)
+    // one context per GPU: parsed + packed once, one RCCL broadcast (rsr_create_group)
+    std::vector<rsr_ctx*> ctxs(size_t(ngpu), nullptr);
+    if (rsr_create_group(ctxs.data(), gpuid.data(), ngpu, tta_mode, parampath.c_str(), modelpath.c_str()) != RSR_OK)
     {
         fprintf(stderr, "model load failed: %s\n", rsr_last_error(nullptr));
         return -1;
     }
-    std::vector<uint8_t> blob(need);
-    if (rsr_model_pack(parampath.c_str(), modelpath.c_str(), blob.data(), blob.size(), &need) != RSR_OK)
-    {
-        fprintf(stderr, "model pack failed: %s\n", rsr_last_error(nullptr));
-        return -1;
-    }
-
+    if (verbose && ngpu > 1) fprintf(stderr, "weights reached %d gpus by: %s\n", ngpu, rsr_group_transport());
     std::vector<std::unique_ptr<RealSR>> realsr;
     for (int i = 0; i < ngpu; i++)
     {
-        std::unique_ptr<RealSR> r(new RealSR(gpuid[size_t(i)], tta_mode != 0, 1));
-        if (!r->ok())
-        {
-            fprintf(stderr, "invalid gpu device\n");
-            return -1;
-        }
-        if (r->load_packed(blob.data(), blob.size()) != RSR_OK) return -1;
+        std::unique_ptr<RealSR> r(new RealSR(ctxs[size_t(i)]));
         r->scale = scale;
         r->tilesize = tilesize[size_t(i)];
         r->prepadding = prepadding;
+        // the reference prints the progress of every tile (realsr.cpp:481); here a batch of tiles runs at once
+        if (verbose)
+            rsr_set_progress_callback(ctxs[size_t(i)], [](int done, int total, void*) { fprintf(stderr, "%.2f%%\n", total ? 100.f * float(done) / float(total) : 100.f); }, nullptr);
         realsr.push_back(std::move(r));
     }
-    blob.clear();
-    blob.shrink_to_fit();
+    // one image, several GPUs: every GPU takes a share of the tile rows
+    const bool split_one_image = ngpu > 1 && input_files.size() == 1;
 
     // load -> proc -> save
     TaskQueue toproc, tosave;
@@ -362,7 +356,15 @@ int main(int argc, char** argv)
                     failures++;
                     continue;
                 }
-                v->outimage.create(v->inimage.w * scale, v->inimage.h * scale, v->inimage.elempack);
+                // an RGBA image cannot be a jpg: write <name>.png instead (main.cpp:278-288)
+                const std::string oext = imgio::lower_ext(v->outpath);
+                if (v->inimage.elempack == 4 && (oext == "jpg" || oext == "jpeg"))
+                {
+                    const std::string out2 = v->outpath + ".png";
+                    fprintf(stderr, "image %s has alpha channel ! %s will output %s\n", v->inpath.c_str(), v->inpath.c_str(), out2.c_str());
+                    v->outpath = out2;
+                }
+                v->outimage.create(v->inimage.w * scale, v->inimage.h * scale, v->inimage.elempack, true);
                 toproc.put(std::move(v));
             }
         });
@@ -375,7 +377,16 @@ int main(int argc, char** argv)
                 {
                     std::unique_ptr<Task> v = toproc.get();
                     if (v->id == kEnd) return;
-                    if (realsr[size_t(g)]->process(v->inimage, v->outimage) != RSR_OK)
+                    int prc;
+                    if (split_one_image)
+                    {
+                        std::vector<RealSR*> grp;
+                        for (auto& r : realsr) grp.push_back(r.get());
+                        prc = RealSR::process_group(grp, v->inimage, v->outimage);
+                    }
+                    else
+                        prc = realsr[size_t(g)]->process(v->inimage, v->outimage);
+                    if (prc != RSR_OK)
                     {
                         std::lock_guard<std::mutex> lk(fail_mu);
                         failures++;
@@ -392,7 +403,7 @@ int main(int argc, char** argv)
             {
                 std::unique_ptr<Task> v = tosave.get();
                 if (v->id == kEnd) return;
-                const std::string err = imgio::save_png(v->outpath, v->outimage);
+                const std::string err = imgio::save_image(v->outpath, v->outimage);
                 if (!err.empty())
                 {
                     fprintf(stderr, "encode image %s failed: %s\n", v->outpath.c_str(), err.c_str());

@@ -69,10 +69,12 @@ def io_harness(tmp_path_factory):
     d = tmp_path_factory.mktemp("io")
     src = d / "t_io.cpp"
     src.write_text('#include "image_io.h"\nint main(int c, char** v){Image im; std::string e = imgio::load_image(v[1], im);'
-                   'if(!e.empty()){fprintf(stderr,"%s\\n",e.c_str());return 1;} e = imgio::save_png(v[2], im);'
+                   'if(!e.empty()){fprintf(stderr,"%s\\n",e.c_str());return 1;} e = imgio::save_image(v[2], im);'
                    'if(!e.empty()){fprintf(stderr,"%s\\n",e.c_str());return 2;} printf("%d %d %d\\n",im.w,im.h,im.elempack);return 0;}\n')
     exe = d / "t_io"
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", CSRC, "-o", str(exe), str(src), "-lz"])
+    lib = os.path.join(ROOT, "realsr-ncnn-vulkan_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", CSRC, "-o", str(exe), str(src), "-L", lib, "-lrealsr_hip",
+                           "-Wl,-rpath," + lib, "-lz"])
     return str(exe)
 
 
@@ -99,9 +101,48 @@ def test_pnm_and_unsupported_formats(io_harness, tmp_path):
         f.write(b"P6\n# c\n4 5\n255\n" + img.tobytes())
     subprocess.check_call([io_harness, str(tmp_path / "a.ppm"), str(tmp_path / "o.png")], stdout=subprocess.DEVNULL)
     assert (read_png(tmp_path / "o.png") == img).all()
-    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 20)
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 20)  # a truncated jpg: decode failure (main.cpp:292-299)
     r = subprocess.run([io_harness, str(tmp_path / "x.jpg"), str(tmp_path / "o2.png")], capture_output=True)
-    assert r.returncode == 1 and b"jpeg" in r.stderr
+    assert r.returncode == 1
+    (tmp_path / "x.webp").write_bytes(b"RIFF\x10\0\0\0WEBPVP8 " + b"\0" * 16)
+    r = subprocess.run([io_harness, str(tmp_path / "x.webp"), str(tmp_path / "o3.png")], capture_output=True)
+    assert r.returncode == 1 and b"webp" in r.stderr
+
+
+def test_jpg_roundtrip_and_png_features(io_harness, tmp_path):
+    """stb codecs as in the reference (main.cpp:208-267, 339-416): jpg encode at quality 100 and decode again; a PNG with a
+    tRNS colour key gets its alpha channel (stb semantics); a 16-bit PNG is reduced to 8 bit."""
+    yy, xx = np.mgrid[0:48, 0:64]
+    img = np.stack([(xx * 4) % 256, (yy * 5) % 256, ((xx + yy) * 2) % 256], 2).astype(np.uint8)  # smooth: jpg keeps it close
+    write_png(tmp_path / "g.png", img)
+    subprocess.check_call([io_harness, str(tmp_path / "g.png"), str(tmp_path / "g.jpg")], stdout=subprocess.DEVNULL)
+    assert open(tmp_path / "g.jpg", "rb").read(3) == b"\xff\xd8\xff"
+    out = subprocess.check_output([io_harness, str(tmp_path / "g.jpg"), str(tmp_path / "g2.png")]).decode().split()
+    assert [int(v) for v in out] == [64, 48, 3]
+    back = read_png(tmp_path / "g2.png").astype(int)
+    assert np.abs(back - img.astype(int)).mean() < 2.0
+    # RGB png + tRNS colour key (0,0,0) -> RGBA with alpha 0 exactly on the keyed pixels
+    key = img.copy()
+    key[:4, :4] = 0
+    h, w = key.shape[:2]
+    raw = b"".join(b"\0" + r.tobytes() for r in key.reshape(h, w * 3))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(tmp_path / "k.png", "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"tRNS", b"\0" * 6)
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    out = subprocess.check_output([io_harness, str(tmp_path / "k.png"), str(tmp_path / "k2.png")]).decode().split()
+    assert int(out[2]) == 4
+    k2 = read_png(tmp_path / "k2.png")
+    assert (k2[:4, :4, 3] == 0).all() and (k2[8:, 8:, 3] == 255).all() and (k2[..., :3] == key).all()
+    # 16-bit RGB -> 8 bit (high byte)
+    raw16 = b"".join(b"\0" + np.stack([r, r], -1).astype(np.uint8).tobytes() for r in img.reshape(h, w * 3))
+    with open(tmp_path / "s.png", "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw16, 6))
+                + chunk(b"IEND", b""))
+    subprocess.check_call([io_harness, str(tmp_path / "s.png"), str(tmp_path / "s2.png")], stdout=subprocess.DEVNULL)
+    assert (read_png(tmp_path / "s2.png") == img).all()
 
 
 def run_cli(*args):
@@ -124,7 +165,7 @@ def test_cli_flag_validation(tmp_path):
     assert "unknown model dir type" in run_cli("-i", str(png), "-o", out, "-m", "models-foo").stderr
     assert "either file or directory" in run_cli("-i", str(png), "-o", str(tmp_path)).stderr
     assert "no CPU fallback" in run_cli("-i", str(png), "-o", out, "-g", "-1").stderr
-    assert "not built in" in run_cli("-i", str(png), "-o", str(tmp_path / "o.jpg")).stderr
+    assert "not built in" in run_cli("-i", str(png), "-o", str(tmp_path / "o.webp")).stderr
 
 
 @pytest.mark.gpu
@@ -151,3 +192,43 @@ def test_cli_directory_run_matches_library(tmp_path, model_dir):
     assert (read_png(outd / (second + ".png")) == sr.process(imgs[key[second]])).all()
     assert (read_png(outd / "b.png") == sr.process(imgs["b"])).all()
     sr.close()
+
+
+@pytest.mark.gpu
+def test_cli_jpg_directory_and_threads(tmp_path, model_dir):
+    """-j 2:4:2 over a directory of jpg + RGBA png inputs, jpg output: 4 proc threads share one context (main.cpp:811-828);
+    the RGBA image cannot be a jpg and is written as <name>.jpg.png (main.cpp:278-288).  The png outputs equal the library
+    byte for byte; the jpg outputs decode to within the codec's error of it."""
+    ind, outd, tmp = tmp_path / "in", tmp_path / "out", tmp_path / "tmp"
+    for d in (ind, outd, tmp):
+        d.mkdir()
+    io_src = tmp / "t_io.cpp"
+    io_src.write_text('#include "image_io.h"\nint main(int c, char** v){Image im; std::string e = imgio::load_image(v[1], im);'
+                      'if(!e.empty()) return 1; e = imgio::save_image(v[2], im); return e.empty() ? 0 : 2;}\n')
+    lib = os.path.join(ROOT, "realsr-ncnn-vulkan_amd", "lib")
+    conv = str(tmp / "t_io")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", CSRC, "-o", conv, str(io_src), "-L", lib, "-lrealsr_hip", "-Wl,-rpath," + lib, "-lz"])
+    sr = R.RealSR(0)
+    sr.load(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
+    sr.tilesize = 32
+    want = {}
+    for i, (w, h) in enumerate([(40, 30), (33, 21), (52, 47), (24, 64), (45, 45), (70, 20)]):
+        img = synth.make_image(60 + i, w, h)
+        write_png(tmp / "p.png", img)
+        subprocess.check_call([conv, str(tmp / "p.png"), str(ind / ("j%d.jpg" % i))])
+        subprocess.check_call([conv, str(ind / ("j%d.jpg" % i)), str(tmp / "back.png")])  # what the CLI will decode
+        want["j%d.jpg" % i] = sr.process(read_png(tmp / "back.png"))
+    rgba = synth.make_image(70, 37, 29, 4)
+    write_png(ind / "r.png", rgba)
+    want["r.jpg.png"] = sr.process(rgba)
+    sr.close()
+    r = run_cli("-i", str(ind), "-o", str(outd), "-m", model_dir, "-t", "32", "-j", "2:4:2", "-f", "jpg", "-v")
+    assert r.returncode == 0, r.stderr
+    assert "r.png has alpha channel" in r.stderr
+    assert sorted(os.listdir(outd)) == sorted(want)
+    assert (read_png(outd / "r.jpg.png") == want["r.jpg.png"]).all()
+    for name in want:
+        if name.endswith(".jpg"):
+            subprocess.check_call([conv, str(outd / name), str(tmp / "o.png")])
+            d = np.abs(read_png(tmp / "o.png").astype(int) - want[name].astype(int))
+            assert d.mean() < 2.5, (name, d.mean())

@@ -261,6 +261,66 @@ def test_corrupt_blob_is_refused_and_state_survives(paths, sr):
     s2.close()
 
 
+# ---- several GPUs: group creation, tile-row sharding of one image ------------------------------------------------------
+def test_tile_rows_and_group_processing_equal_the_full_image(paths):
+    """one large image split by tile rows.  Two contexts (both on GPU 0 here) each process a disjoint range of
+    tile rows into ONE output buffer; rsr_process_group does the same on its own threads.  Bytes identical to one call."""
+    a, b = R.RealSR(0), R.RealSR(0)
+    for s in (a, b):
+        s.load(*paths)
+        s.tilesize = 32
+    img = synth.make_image(55, 70, 150)  # 3 x 5 tiles
+    want = a.process(img)
+    out = np.zeros_like(want)
+    a.process_rows(img, out, 0, 2)
+    assert (out[:2 * 32 * 4] == want[:2 * 32 * 4]).all() and (out[2 * 32 * 4:] == 0).all()
+    b.process_rows(img, out, 2, 5)
+    assert (out == want).all()
+    assert (R.process_group([a, b], img) == want).all()
+    assert (R.process_group([a], img) == want).all()
+    rgba = synth.make_image(56, 40, 100, 4)
+    assert (R.process_group([a, b], rgba) == a.process(rgba)).all()
+    with pytest.raises(R.RealSRError) as e:
+        a.process_rows(img, out, 3, 9)
+    assert e.value.code == R.RSR_E_ARG
+    a.close()
+    b.close()
+
+
+def test_create_group(paths):
+    """rsr_create_group: parse + pack once, one context per GPU (one GPU here: no collective needed); a duplicate id and a
+    missing device are argument / device errors and leave no context behind."""
+    srs, transport = R.create_group([0], *paths)
+    assert len(srs) == 1 and transport.startswith("host")
+    srs[0].tilesize = 32
+    img = synth.make_image(57, 40, 30)
+    ref = R.RealSR(0)
+    ref.load(*paths)
+    ref.tilesize = 32
+    assert (srs[0].process(img) == ref.process(img)).all()
+    ref.close()
+    srs[0].close()
+    with pytest.raises(R.RealSRError) as e:
+        R.create_group([0, 0], *paths)
+    assert e.value.code == R.RSR_E_ARG
+    import torch
+    if torch.cuda.device_count() == 1:
+        with pytest.raises(R.RealSRError) as e:
+            R.create_group([0, 1], *paths)
+        assert e.value.code == R.RSR_E_DEVICE
+    else:  # a multi-GPU box: the real thing, weights by RCCL broadcast
+        srs, transport = R.create_group([0, 1], *paths)
+        assert transport == "rccl", transport
+        for s in srs:
+            s.tilesize = 32
+        big = synth.make_image(58, 70, 150)
+        one = srs[0].process(big)
+        assert (srs[1].process(big) == one).all()
+        assert (R.process_group(srs, big) == one).all()
+        for s in srs:
+            s.close()
+
+
 # ---- bench.py's multi-rank control flow, executed on ONE gpu (the driver's 8-GPU run is the first real one otherwise) ----------
 def test_bench_multirank_control_flow_on_one_gpu(tmp_path):
     env = dict(os.environ, RSR_BENCH_SAME_GPU="1", RSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")

@@ -83,7 +83,9 @@ __device__ __forceinline__ WorkItem load_item(const WorkItem* items, int idx)
     it.x0 = __builtin_amdgcn_readfirstlane(v[2]);
     it.H = __builtin_amdgcn_readfirstlane(v[3]);
     it.W = __builtin_amdgcn_readfirstlane(v[4]);
-    it.pad0 = it.pad1 = it.pad2 = 0;
+    it.pad0 = __builtin_amdgcn_readfirstlane(v[5]);
+    it.pad1 = __builtin_amdgcn_readfirstlane(v[6]);
+    it.pad2 = __builtin_amdgcn_readfirstlane(v[7]);
     return it;
 }
 
@@ -361,12 +363,38 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         for (int p = 0; p < 2; p++)
             __builtin_amdgcn_raw_buffer_store_b128(tq[p], rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride), 0, 0);
     };
-    // conv_last (EPI 0): channels 0..2 of n-tile 0 -> planar fp16 [3][H][W]
+    // conv_last (EPI 0): channels 0..2 of n-tile 0 -> planar fp16 [3][H][W] (the reference's `output` blob, consumed by
+    // postproc_tiles), or -- non-TTA RGB -- straight into the uint8 image: realsr_postproc.comp:62-83 on the value rounded to
+    // fp16 exactly as the planar path stores it (v*255 + 0.5, floor, clamp), at the tile's place minus the halo crop.
     auto planar_store = [&](const f32x16 (&acc)[4][NTW], const WorkItem& it) {
         if (hi != 0 || ntw0 != 0 || (a.dbg & 4)) return;
+        const int x = it.x0 + l32;
+        if (a.out_u8)
+        {
+            const int ox = it.pad0 + x, ow = it.pad2 & 0xffff, oh = it.pad2 >> 16;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+            {
+                const int y = it.y0 + wrow * 4 + rr;
+                // (x - crop, y - crop) inside the un-padded rectangle  <=>  image pixel (pad0 + x, pad1 + y) inside the tile's box
+                const int rx = x - a.out_u8_crop, ry = y - a.out_u8_crop;
+                if (rx >= 0 && rx < ow && ry >= 0 && ry < oh)
+                {
+                    uint8_t* o = a.out_u8 + ((long long)(it.pad1 + y) * a.out_u8_w + ox) * 3;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                    {
+                        float v = (float)(_Float16)acc[rr][0][ch];
+                        v = floorf(v * 255.f + 0.5f);
+                        v = fminf(fmaxf(v, 0.f), 255.f);
+                        o[ch] = (uint8_t)v;
+                    }
+                }
+            }
+            return;
+        }
         _Float16* o = reinterpret_cast<_Float16*>(static_cast<char*>(a.out_planar3) + (long long)it.slot * a.planar3_slot_stride);
         const long long hw = (long long)it.H * it.W;
-        const int x = it.x0 + l32;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++)
         {
@@ -540,7 +568,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     auto item_from_q = [&]() {
         WorkItem w;
         w.slot = item_q[0]; w.y0 = item_q[1]; w.x0 = item_q[2]; w.H = item_q[3]; w.W = item_q[4];
-        w.pad0 = w.pad1 = w.pad2 = 0;
+        w.pad0 = item_q[5]; w.pad1 = item_q[6]; w.pad2 = item_q[7];
         return w;
     };
 
@@ -871,7 +899,7 @@ bool launch_conv_flow(const ConvArgs& a, int nt, int ncu, int flags, hipStream_t
         else if (a.res1_kind == 1 && (a.res2_kind == 0 || a.res2_kind == 1)) epi = 2;
         else return false;
     }
-    else if (!a.out_planar3 || a.out16.base || a.out32a.base || a.out32b.base || a.res1_kind || a.res2_kind) return false;
+    else if ((!a.out_planar3 && !a.out_u8) || a.out16.base || a.out32a.base || a.out32b.base || a.res1_kind || a.res2_kind) return false;
     const bool ntw2 = (flags & 1) != 0, defer = !(flags & 2);
     if (nt == 1)
     {

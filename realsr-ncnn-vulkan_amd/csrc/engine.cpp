@@ -196,7 +196,8 @@ void Engine::free_plans()
     plans.clear();
 }
 
-static void make_items(Plan::Batch& b)
+// crop4 = prepadding * scale, or < 0 when the slots are not the tiles themselves (TTA: 8 slots per tile, net_forward)
+static void make_items(Plan::Batch& b, int crop4 = -1)
 {
     for (int lvl = 0; lvl < 3; lvl++)
     {
@@ -206,8 +207,17 @@ static void make_items(Plan::Batch& b)
         {
             const int H = b.dims[size_t(s)].h << lvl, W = b.dims[size_t(s)].w << lvl;
             b.px[lvl] += double(H) * W;
+            // 4x-level items carry the tile's placement in the output image: conv_last can write the uint8 image itself
+            int p0 = 0, p1 = 0, p2 = 0;
+            if (lvl == 2 && crop4 >= 0 && size_t(s) < b.tiles.size())
+            {
+                const BaseTile& t = b.tiles[size_t(s)];
+                p0 = t.out_x - crop4;
+                p1 = t.out_y - crop4;
+                p2 = t.out_w | (t.out_h << 16);
+            }
             for (int y0 = 0; y0 < H; y0 += kBlkH)
-                for (int x0 = 0; x0 < W; x0 += kBlkW) b.items[lvl].push_back(WorkItem{s, y0, x0, H, W, 0, 0, 0});
+                for (int x0 = 0; x0 < W; x0 += kBlkW) b.items[lvl].push_back(WorkItem{s, y0, x0, H, W, p0, p1, p2});
         }
     }
 }
@@ -324,7 +334,7 @@ int Engine::get_plan(int w, int h, int c, int row0, int row1, Plan*& out)
             for (int k = 0; k < per; k++)
                 b.dims.push_back(k < 4 ? TileDim{t.th, t.tw} : TileDim{t.tw, t.th}); // realsr.cpp:251-258
         }
-        make_items(b);
+        make_items(b, tta ? -1 : P * scale);
         table_bytes += batch_table_bytes(b);
         plan.batches.push_back(std::move(b));
     }
@@ -492,7 +502,7 @@ int Engine::launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st)
     return RSR_OK;
 }
 
-int Engine::run_network(const Plan::Batch& b, hipStream_t st)
+int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out, int fused_out_w)
 {
     const long long cap = ws_cap_px;
     const int pc = plane_ch(), P32 = 32 / pc, P64 = 64 / pc;
@@ -612,8 +622,17 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st)
     { // conv_last 64 -> 3   (x4.param:1001), planar fp16 output = the reference's `output` blob
         ConvArgs a = base_args(2, 2);
         a.src0 = hr; a.n0 = P64;
-        a.out_planar3 = b_out3.p;
-        a.planar3_slot_stride = cap * 96;
+        if (fused_out)
+        { // non-TTA RGB with conv3x3_flow: conv_last applies realsr_postproc.comp itself and writes the image
+            a.out_u8 = fused_out;
+            a.out_u8_w = fused_out_w;
+            a.out_u8_crop = prepadding * scale;
+        }
+        else
+        {
+            a.out_planar3 = b_out3.p;
+            a.planar3_slot_stride = cap * 96;
+        }
         go(a);
     }
     return rc;
@@ -648,8 +667,13 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         pa.plane_ch = pc;
         launch_preproc_tiles(pa, plan.max_tw, plan.max_th, st);
         mark(0, 0, b.px[0] / (tta ? 8 : 1) * c + b.px[0] * 64, st);
-        rc = run_network(b, st);
+        // conv_last writes the uint8 image directly when no TTA merge / alpha channel needs the fp16 blob (dbg 8192: off)
+        const bool fused = !tta && c == 3 && eff_kernel() >= 4 && !(dbg & 8192);
+        rc = run_network(b, st, fused ? static_cast<uint8_t*>(d_out) : nullptr, w * scale);
         if (rc != RSR_OK) return rc;
+        done += b.ntiles;
+        if (progress) progress(done, total, progress_user);
+        if (fused) continue;
         PostArgs po;
         po.planar3 = b_out3.p;
         po.slot_stride = plan.cap_px * 96;
@@ -665,8 +689,6 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         po.bgr = 0;
         launch_postproc_tiles(po, (plan.max_tw - 2 * prepadding) * scale, (plan.max_th - 2 * prepadding) * scale, st);
         mark(2, 0, b.px[2] / (tta ? 8 : 1) * (6.0 * (tta ? 8 : 1) + c), st);
-        done += b.ntiles;
-        if (progress) progress(done, total, progress_user);
     }
     HIP_TRY(hipGetLastError());
     if (profiling)

@@ -155,7 +155,7 @@ struct Engine
     int ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool layout_changed, bool zero_all, hipStream_t st);
     int get_plan(int w, int h, int c, int row0, int row1, Plan*& out);
     int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
-    int run_network(const Plan::Batch& b, hipStream_t st);
+    int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out = nullptr, int fused_out_w = 0);
     int launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st);
     int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0 = 0, int row1 = -1);
     void mark_begin(hipStream_t st);

@@ -27,6 +27,8 @@ struct WorkItem // 32 bytes: one aligned 2 x 16-byte fetch gives a workgroup eve
 {
     int slot, y0, x0; // tile slot and block origin at this table's resolution level
     int H, W;         // dims of the slot's tile at this level (output dims of the conv)
+    // 4x-level items of a non-TTA batch: image coordinates of tile pixel (0,0) (= out_x - crop, out_y - crop; may be negative)
+    // and the size of the tile's un-padded output rectangle, out_w | out_h << 16  (conv_last writes the image itself)
     int pad0, pad1, pad2;
 };
 
@@ -67,6 +69,10 @@ struct ConvArgs
     // conv_last: planar fp16 [3][H][W] per slot
     void* out_planar3;
     long long planar3_slot_stride; // bytes
+    // conv_last fused with realsr_postproc.comp (non-TTA RGB, conv3x3_flow): uint8 HWC image, row pitch out_u8_w pixels; the
+    // work items of the launch carry the tile's placement (WorkItem::pad0..2, see engine.cpp make_items)
+    uint8_t* out_u8;
+    int out_u8_w, out_u8_crop; // crop = prepadding * scale
     // work
     const WorkItem* items;
     int nitems;

@@ -261,6 +261,22 @@ def test_corrupt_blob_is_refused_and_state_survives(paths, sr):
     s2.close()
 
 
+def test_fused_conv_last_is_bit_identical_to_postproc_kernel(sr):
+    """Non-TTA RGB: conv_last applies realsr_postproc.comp:62-83 itself and writes the uint8 image (no planar fp16 blob, no
+    postproc launch).  dbg 8192 switches back to conv_last -> planar blob -> postproc_tiles: the bytes must be the same,
+    incl. partial tiles, images smaller than a tile, and a 1080p frame at tile 200."""
+    for (w, h, T) in [(50, 43, 32), (5, 3, 32), (130, 70, 64), (1920, 1080, 200)]:
+        sr.tilesize = T
+        img = synth.make_image(90 + w, w, h)
+        fused = sr.process(img)
+        sr.set_option("dbg", 8192)
+        try:
+            two = sr.process(img)
+        finally:
+            sr.set_option("dbg", 0)
+        assert (fused == two).all(), (w, h, T, int((fused != two).sum()))
+
+
 # ---- several GPUs: group creation, tile-row sharding of one image ------------------------------------------------------
 def test_tile_rows_and_group_processing_equal_the_full_image(paths):
     """one large image split by tile rows.  Two contexts (both on GPU 0 here) each process a disjoint range of

@@ -34,7 +34,7 @@ Engine::~Engine()
         if (l->d_out.p) (void)hipFree(l->d_out.p);
         if (l->h_in) (void)hipHostFree(l->h_in);
         if (l->h_out) (void)hipHostFree(l->h_out);
-        for (hipEvent_t e : {l->ev_in, l->ev_done, l->ev_chunk[0], l->ev_chunk[1]})
+        for (hipEvent_t e : {l->ev_in, l->ev_done, l->ev_half, l->ev_chunk[0], l->ev_chunk[1]})
             if (e) (void)hipEventDestroy(e);
         if (l->copy) (void)hipStreamDestroy(l->copy);
     }
@@ -498,11 +498,12 @@ int Engine::launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st)
         else if (kv >= 2) launch_conv_pipe(a, int(c.nt), num_cu, st);
         else launch_conv(a, int(c.nt), use_dma, st);
     }
-    mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out], 0, st, ci);
+    const double frac = b.items[a.lvl_out].empty() ? 1.0 : double(a.nitems) / double(b.items[a.lvl_out].size()); // split launches
+    mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out] * frac, 0, st, ci);
     return RSR_OK;
 }
 
-int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out, int fused_out_w)
+int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out, int fused_out_w, int split_slot, hipEvent_t ev_half)
 {
     const long long cap = ws_cap_px;
     const int pc = plane_ch(), P32 = 32 / pc, P64 = 64 / pc;
@@ -607,41 +608,70 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         a.out16 = up1;
         go(a);
     }
-    { // nearest x2 + upconv2 + lrelu   (x4.param:998-999)
-        ConvArgs a = base_args(1, 2);
-        a.src0 = up1; a.n0 = P64;
-        a.out16 = up2;
-        go(a);
+    // The three convs of the 4x level (upconv2, HRconv, conv_last: ~10 % of the frame, 3 long launches).  With split_slot > 0
+    // they run for the tiles [0, split_slot) first, `ev_half` is recorded, then for the rest: the caller starts downloading
+    // the finished output rows while the second part is still being computed (tiles are independent).  Items are sorted by
+    // slot, so a part is a contiguous range of the item table (a suffix / prefix of the reversed table).
+    const int ci_tail = ci;
+    const int n2 = int(b.items[2].size());
+    int nA = n2;
+    if (split_slot > 0)
+    {
+        nA = 0;
+        while (nA < n2 && b.items[2][size_t(nA)].slot < split_slot) nA++;
     }
-    { // HRconv + lrelu   (x4.param:1000)
-        ConvArgs a = base_args(2, 2);
-        a.src0 = up2; a.n0 = P64;
-        a.out16 = hr;
-        go(a);
-    }
-    { // conv_last 64 -> 3   (x4.param:1001), planar fp16 output = the reference's `output` blob
-        ConvArgs a = base_args(2, 2);
-        a.src0 = hr; a.n0 = P64;
-        if (fused_out)
-        { // non-TTA RGB with conv3x3_flow: conv_last applies realsr_postproc.comp itself and writes the image
-            a.out_u8 = fused_out;
-            a.out_u8_w = fused_out_w;
-            a.out_u8_crop = prepadding * scale;
+    for (int part = 0; part < (nA < n2 ? 2 : 1); part++)
+    {
+        ci = ci_tail;
+        const int i0 = part == 0 ? 0 : nA, cnt = part == 0 ? nA : n2 - nA;
+        auto sub = [&](ConvArgs& a) {
+            const bool rev = a.items == b.d_items_rev[2];
+            a.items = rev ? b.d_items_rev[2] + (n2 - i0 - cnt) : b.d_items[2] + i0;
+            a.nitems = cnt;
+        };
+        { // nearest x2 + upconv2 + lrelu   (x4.param:998-999)
+            ConvArgs a = base_args(1, 2);
+            a.src0 = up1; a.n0 = P64;
+            a.out16 = up2;
+            sub(a);
+            go(a);
         }
-        else
-        {
-            a.out_planar3 = b_out3.p;
-            a.planar3_slot_stride = cap * 96;
+        { // HRconv + lrelu   (x4.param:1000)
+            ConvArgs a = base_args(2, 2);
+            a.src0 = up2; a.n0 = P64;
+            a.out16 = hr;
+            sub(a);
+            go(a);
         }
-        go(a);
+        { // conv_last 64 -> 3   (x4.param:1001), planar fp16 output = the reference's `output` blob
+            ConvArgs a = base_args(2, 2);
+            a.src0 = hr; a.n0 = P64;
+            if (fused_out)
+            { // non-TTA RGB with conv3x3_flow: conv_last applies realsr_postproc.comp itself and writes the image
+                a.out_u8 = fused_out;
+                a.out_u8_w = fused_out_w;
+                a.out_u8_crop = prepadding * scale;
+            }
+            else
+            {
+                a.out_planar3 = b_out3.p;
+                a.planar3_slot_stride = cap * 96;
+            }
+            sub(a);
+            go(a);
+        }
+        if (part == 0 && nA < n2 && ev_half && rc == RSR_OK && hipEventRecord(ev_half, st) != hipSuccess)
+            rc = fail(RSR_E_DEVICE, "hipEventRecord failed");
     }
     return rc;
 }
 
 // ---- process ----------------------------------------------------------------------------------
 // enqueue preproc -> network -> postproc for every tile batch of one image on `st` (mu held)
-int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0, int row1)
+int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0, int row1, hipEvent_t ev_half,
+                          size_t* half_rows)
 {
+    if (half_rows) *half_rows = 0;
     Plan* planp = nullptr;
     if (row1 < 0) row1 = (h + tilesize - 1) / tilesize;
     int rc = get_plan(w, h, c, row0, row1, planp);
@@ -669,7 +699,18 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         mark(0, 0, b.px[0] / (tta ? 8 : 1) * c + b.px[0] * 64, st);
         // conv_last writes the uint8 image directly when no TTA merge / alpha channel needs the fp16 blob (dbg 8192: off)
         const bool fused = !tta && c == 3 && eff_kernel() >= 4 && !(dbg & 8192);
-        rc = run_network(b, st, fused ? static_cast<uint8_t*>(d_out) : nullptr, w * scale);
+        // host calls: split the 4x tail at a tile-row boundary so that the first output rows can travel while the rest is computed
+        int split_slot = 0;
+        if (fused && ev_half && half_rows && plan.batches.size() == 1 && !profiling && !(dbg & 16384))
+        {
+            const int xt = (w + tilesize - 1) / tilesize, yt = b.ntiles / xt;
+            if (yt >= 2 && b.ntiles == xt * yt)
+            {
+                split_slot = xt * (yt / 2);
+                *half_rows = size_t(b.tiles[size_t(split_slot)].out_y - b.tiles[0].out_y); // output rows finished at ev_half
+            }
+        }
+        rc = run_network(b, st, fused ? static_cast<uint8_t*>(d_out) : nullptr, w * scale, split_slot, ev_half);
         if (rc != RSR_OK) return rc;
         done += b.ntiles;
         if (progress) progress(done, total, progress_user);
@@ -821,7 +862,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     if (!L->copy)
     {
         HIP_TRY(hipStreamCreateWithFlags(&L->copy, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&L->ev_in, &L->ev_done, &L->ev_chunk[0], &L->ev_chunk[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&L->ev_in, &L->ev_done, &L->ev_half, &L->ev_chunk[0], &L->ev_chunk[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     int rc;
     if ((rc = ensure(L->d_in, nin)) != RSR_OK) return rc;  // lane-private: nothing else can be using the old allocation
@@ -839,7 +880,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     HIP_TRY(hipEventRecord(L->ev_in, L->copy));
 
     // ---- network ----
-    size_t out_off = 0, nout = nout_full;
+    size_t out_off = 0, nout = nout_full, half_rows = 0;
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!loaded) return fail(RSR_E_STATE, "process before load");
@@ -856,7 +897,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
         const size_t rowbytes = size_t(w) * scale * c;
         out_off = size_t(row0) * tilesize * scale * rowbytes;
         nout = size_t(std::min(row1 * tilesize, h) - row0 * tilesize) * scale * rowbytes;
-        rc = enqueue_image(L->d_in.p, w, h, c, L->d_out.p, stream, row0, row1);
+        rc = enqueue_image(L->d_in.p, w, h, c, L->d_out.p, stream, row0, row1, L->ev_half, &half_rows);
         if (rc != RSR_OK)
         {
             (void)hipStreamSynchronize(L->copy);
@@ -864,26 +905,43 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
         }
         HIP_TRY(hipEventRecord(L->ev_done, stream));
     }
-    HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_done, 0));
 
     // ---- download ----
+    // When the engine split the 4x tail, the first `half_rows` output rows are complete at ev_half: they travel while the second
+    // part is still being computed.
     out += out_off;
-    if (is_pinned_host(out))
+    const size_t first = std::min(nout, half_rows * size_t(w) * scale * c);
+    const bool pinned_out = is_pinned_host(out);
+    if (pinned_out)
     {
-        HIP_TRY(hipMemcpyAsync(out, static_cast<const char*>(L->d_out.p) + out_off, nout, hipMemcpyDeviceToHost, L->copy));
+        const char* dsrc = static_cast<const char*>(L->d_out.p) + out_off;
+        if (first)
+        {
+            HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_half, 0));
+            HIP_TRY(hipMemcpyAsync(out, dsrc, first, hipMemcpyDeviceToHost, L->copy));
+        }
+        HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_done, 0));
+        HIP_TRY(hipMemcpyAsync(out + first, dsrc + first, nout - first, hipMemcpyDeviceToHost, L->copy));
         HIP_TRY(hipStreamSynchronize(L->copy));
         return RSR_OK;
     }
+    HIP_TRY(hipStreamWaitEvent(L->copy, first ? L->ev_half : L->ev_done, 0));
     const size_t CH = std::max<size_t>(chunk_bytes, 1 << 20);
     if ((rc = ensure_pinned(L->h_out, L->h_out_bytes, 2 * std::min(CH, nout))) != RSR_OK) return rc;
     const size_t half = L->h_out_bytes / 2;
     const size_t nchunks = (nout + half - 1) / half;
     const char* dsrc = static_cast<const char*>(L->d_out.p) + out_off;
+    bool waited_done = false;
     for (size_t i = 0; i <= nchunks; i++)
     {
         if (i < nchunks)
         {
             const size_t off = i * half, n = std::min(half, nout - off);
+            if (first && !waited_done && off + n > first)
+            { // this chunk reaches into the rows of the second part
+                HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_done, 0));
+                waited_done = true;
+            }
             // slot i&1 was drained by the CPU copy of chunk i-2 in the previous iteration
             HIP_TRY(hipMemcpyAsync(static_cast<char*>(L->h_out) + (i & 1) * half, dsrc + off, n, hipMemcpyDeviceToHost, L->copy));
             HIP_TRY(hipEventRecord(L->ev_chunk[i & 1], L->copy));

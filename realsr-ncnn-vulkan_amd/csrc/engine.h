@@ -64,7 +64,7 @@ struct Plan
 struct Lane
 {
     hipStream_t copy = nullptr;
-    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_chunk[2] = {nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_half = nullptr, ev_chunk[2] = {nullptr, nullptr};
     DevBuf d_in, d_out;
     void* h_in = nullptr;
     size_t h_in_bytes = 0;
@@ -155,9 +155,11 @@ struct Engine
     int ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool layout_changed, bool zero_all, hipStream_t st);
     int get_plan(int w, int h, int c, int row0, int row1, Plan*& out);
     int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
-    int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out = nullptr, int fused_out_w = 0);
+    int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out = nullptr, int fused_out_w = 0, int split_slot = 0,
+                    hipEvent_t ev_half = nullptr);
     int launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st);
-    int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0 = 0, int row1 = -1);
+    int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0 = 0, int row1 = -1,
+                      hipEvent_t ev_half = nullptr, size_t* half_rows = nullptr);
     void mark_begin(hipStream_t st);
     void mark(int cls, double flops, double bytes, hipStream_t st, int conv_index = -1);
     void collect_profile(hipStream_t st);

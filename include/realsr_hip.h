@@ -210,6 +210,11 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                       in fp32 (halves the pre-quantise error; served by the kernel-3 path, ~-25 % throughput)
  *   "flow_flags"        kernel 4: bit 0 = 64-output-channel convs with 4 MFMA waves x 64 channels instead of 8 x 32,
  *                       bit 1 = no deferred epilogue for the 32-output-channel convs
+ *   "tail_group"        slots (tiles; x8 under TTA) per launch group of the 2x / 4x convs (default 0 = the whole batch at once).  Small
+ *                       groups keep the 4x intermediates in the Infinity Cache between upconv2 -> HRconv -> conv_last; measured
+ *                       worth <= 1.5 % of those launches on MI355X and a loss at the 2x level, hence off
+ *   "bgr"               1: the caller's images are BGR(A) (the reference's Windows build: WIC decodes to BGR, realsr.cpp:188-206,
+ *                       497-515, realsr_preproc.comp:17-21); the network always sees RGB.  Default 0 = RGB(A)
  *   "use_dma"           kernel 1 only: LDS-DMA (1) or register staging (0)
  *   "max_lanes"         rsr_process calls in flight per context (default 4); "chunk_mb": download chunk for pageable
  *                       destinations (default 16)

@@ -348,6 +348,13 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     }
     else if (k == "trunk_fp32")
         ctx->e.trunk_fp32 = value != 0;
+    else if (k == "tail_group")
+    {
+        if (value < 0) return ctx->e.fail(RSR_E_ARG, "tail_group must be >= 0");
+        ctx->e.tail_group_slots = int(value);
+    }
+    else if (k == "bgr")
+        ctx->e.bgr = value != 0;
     else if (k == "use_dma")
         ctx->e.use_dma = value != 0;
     else if (k == "kernel")

@@ -387,7 +387,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                         float v = (float)(_Float16)acc[rr][0][ch];
                         v = floorf(v * 255.f + 0.5f);
                         v = fminf(fmaxf(v, 0.f), 255.f);
-                        o[ch] = (uint8_t)v;
+                        o[a.out_u8_bgr ? 2 - ch : ch] = (uint8_t)v;
                     }
                 }
             }

@@ -202,9 +202,11 @@ static void make_items(Plan::Batch& b, int crop4 = -1)
     for (int lvl = 0; lvl < 3; lvl++)
     {
         b.items[lvl].clear();
+        b.item_start[lvl].assign(size_t(b.nslots) + 1, 0);
         b.px[lvl] = 0;
         for (int s = 0; s < b.nslots; s++)
         {
+            b.item_start[lvl][size_t(s)] = int(b.items[lvl].size());
             const int H = b.dims[size_t(s)].h << lvl, W = b.dims[size_t(s)].w << lvl;
             b.px[lvl] += double(H) * W;
             // 4x-level items carry the tile's placement in the output image: conv_last can write the uint8 image itself
@@ -219,6 +221,7 @@ static void make_items(Plan::Batch& b, int crop4 = -1)
             for (int y0 = 0; y0 < H; y0 += kBlkH)
                 for (int x0 = 0; x0 < W; x0 += kBlkW) b.items[lvl].push_back(WorkItem{s, y0, x0, H, W, p0, p1, p2});
         }
+        b.item_start[lvl][size_t(b.nslots)] = int(b.items[lvl].size());
     }
 }
 
@@ -602,45 +605,47 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
     }
     const PlaneSrc up1 = PS(b_up1, P64, cap * 4 * ppx + kGuard, 0), up2 = PS(b_up2, P64, cap * 16 * ppx + kGuard, 0),
                    hr = PS(b_hr, P64, cap * 16 * ppx + kGuard, 0);
-    { // nearest x2 + upconv1 + lrelu   (x4.param:996-997)
-        ConvArgs a = base_args(0, 1);
-        a.src0 = rdb_x(1); a.n0 = P64;
-        a.out16 = up1;
-        go(a);
-    }
-    // The three convs of the 4x level (upconv2, HRconv, conv_last: ~10 % of the frame, 3 long launches).  With split_slot > 0
-    // they run for the tiles [0, split_slot) first, `ev_half` is recorded, then for the rest: the caller starts downloading
-    // the finished output rows while the second part is still being computed (tiles are independent).  Items are sorted by
-    // slot, so a part is a contiguous range of the item table (a suffix / prefix of the reversed table).
+    // The convs behind the trunk (upconv1 @2x, upconv2 / HRconv / conv_last @4x: ~11 % of the frame) can run per GROUP of
+    // `tail_group_slots` slots (0 = the whole batch): a tile has 4x / 16x the blocks up there, so a few tiles fill the chip for
+    // > 100 us per launch, and their 2 x 99 MB per tile of 4x intermediates are then read back from the 256 MB Infinity Cache
+    // instead of HBM.  Measured on MI355X: <= 1.5 % on the 4x launches, a loss at 2x -- HBM bytes are not what bounds this
+    // workload, so the default is off.  With split_slot > 0 a group boundary is forced there and `ev_half` is
+    // recorded behind it: the caller starts downloading the finished output rows while the remaining groups are computed
+    // (tiles are independent).  Items are sorted by slot, so a group is a contiguous range of the item tables (mirrored in
+    // the reversed tables).
     const int ci_tail = ci;
-    const int n2 = int(b.items[2].size());
-    int nA = n2;
-    if (split_slot > 0)
+    const int gsz = tail_group_slots > 0 ? tail_group_slots : b.nslots;
+    for (int s0 = 0; s0 < b.nslots && rc == RSR_OK;)
     {
-        nA = 0;
-        while (nA < n2 && b.items[2][size_t(nA)].slot < split_slot) nA++;
-    }
-    for (int part = 0; part < (nA < n2 ? 2 : 1); part++)
-    {
+        int s1 = std::min(b.nslots, s0 + gsz);
+        if (split_slot > s0 && split_slot < s1) s1 = split_slot;
         ci = ci_tail;
-        const int i0 = part == 0 ? 0 : nA, cnt = part == 0 ? nA : n2 - nA;
-        auto sub = [&](ConvArgs& a) {
-            const bool rev = a.items == b.d_items_rev[2];
-            a.items = rev ? b.d_items_rev[2] + (n2 - i0 - cnt) : b.d_items[2] + i0;
+        auto sub = [&](ConvArgs& a, int lvl) {
+            const int n = int(b.items[lvl].size());
+            const int i0 = b.item_start[lvl][size_t(s0)], cnt = b.item_start[lvl][size_t(s1)] - i0;
+            const bool rev = a.items == b.d_items_rev[lvl];
+            a.items = rev ? b.d_items_rev[lvl] + (n - i0 - cnt) : b.d_items[lvl] + i0;
             a.nitems = cnt;
         };
+        { // nearest x2 + upconv1 + lrelu   (x4.param:996-997)
+            ConvArgs a = base_args(0, 1);
+            a.src0 = rdb_x(1); a.n0 = P64;
+            a.out16 = up1;
+            sub(a, 1);
+            go(a);
+        }
         { // nearest x2 + upconv2 + lrelu   (x4.param:998-999)
             ConvArgs a = base_args(1, 2);
             a.src0 = up1; a.n0 = P64;
             a.out16 = up2;
-            sub(a);
+            sub(a, 2);
             go(a);
         }
         { // HRconv + lrelu   (x4.param:1000)
             ConvArgs a = base_args(2, 2);
             a.src0 = up2; a.n0 = P64;
             a.out16 = hr;
-            sub(a);
+            sub(a, 2);
             go(a);
         }
         { // conv_last 64 -> 3   (x4.param:1001), planar fp16 output = the reference's `output` blob
@@ -651,17 +656,19 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
                 a.out_u8 = fused_out;
                 a.out_u8_w = fused_out_w;
                 a.out_u8_crop = prepadding * scale;
+                a.out_u8_bgr = bgr ? 1 : 0;
             }
             else
             {
                 a.out_planar3 = b_out3.p;
                 a.planar3_slot_stride = cap * 96;
             }
-            sub(a);
+            sub(a, 2);
             go(a);
         }
-        if (part == 0 && nA < n2 && ev_half && rc == RSR_OK && hipEventRecord(ev_half, st) != hipSuccess)
+        if (s1 == split_slot && ev_half && rc == RSR_OK && hipEventRecord(ev_half, st) != hipSuccess)
             rc = fail(RSR_E_DEVICE, "hipEventRecord failed");
+        s0 = s1;
     }
     return rc;
 }
@@ -693,7 +700,7 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         pa.tta = tta;
         pa.in_plane = static_cast<char*>(b_in.p) + kGuard;
         pa.slot_stride = (32 / pc) * (plan.cap_px * pc * 2 + kGuard);
-        pa.bgr = 0;
+        pa.bgr = bgr ? 1 : 0;
         pa.plane_ch = pc;
         launch_preproc_tiles(pa, plan.max_tw, plan.max_th, st);
         mark(0, 0, b.px[0] / (tta ? 8 : 1) * c + b.px[0] * 64, st);
@@ -727,7 +734,7 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         po.in_img = static_cast<const uint8_t*>(d_in);
         po.in_w = w; po.in_h = h;
         po.tilesize = tilesize;
-        po.bgr = 0;
+        po.bgr = bgr ? 1 : 0;
         launch_postproc_tiles(po, (plan.max_tw - 2 * prepadding) * scale, (plan.max_th - 2 * prepadding) * scale, st);
         mark(2, 0, b.px[2] / (tta ? 8 : 1) * (6.0 * (tta ? 8 : 1) + c), st);
     }

@@ -48,6 +48,7 @@ struct Plan
         std::vector<BaseTile> tiles; // slot0 relative to the batch
         std::vector<TileDim> dims;   // per slot
         std::vector<WorkItem> items[3];
+        std::vector<int> item_start[3]; // first item of every slot (+ end): items are sorted by slot
         double px[3] = {0, 0, 0}; // sum over slots of H*W at each level (for FLOP accounting)
         // device copies
         BaseTile* d_tiles = nullptr;
@@ -81,6 +82,7 @@ struct Engine
     bool loaded = false;
     bool trunk_fp32 = false; // residual trunk storage: fp16 like the reference Vulkan path (realsr.cpp:45); true = extra fp32 copy (kernels 1-3)
     bool use_dma = true;
+    bool bgr = false; // pixel order of the caller's images: BGR(A) like the reference's Windows/WIC path (realsr.cpp:188-206,497-515)
     // 4: conv3x3_flow on 16-channel planes (default); 3: conv3x3_ring + conv3x3_pipe, 2: conv3x3_pipe, 1: conv3x3_mfma (32-channel planes)
     int kernel_version = 4;
     int flow_flags = 0; // launch_conv_flow flags
@@ -90,6 +92,7 @@ struct Engine
     int trace_conv = -1; // conv index whose launch records s_memtime stamps into trace_buf (profiling only)
     DevBuf trace_buf;
     long long max_workspace_mb = 65536;
+    int tail_group_slots = 0; // slots per launch group of the 2x / 4x convs (0 = the whole batch at once), see run_network
     int max_lanes = 4;
     size_t chunk_bytes = size_t(16) << 20; // download chunk for pageable destinations
     hipStream_t stream = nullptr;          // the compute stream

@@ -72,7 +72,7 @@ struct ConvArgs
     // conv_last fused with realsr_postproc.comp (non-TTA RGB, conv3x3_flow): uint8 HWC image, row pitch out_u8_w pixels; the
     // work items of the launch carry the tile's placement (WorkItem::pad0..2, see engine.cpp make_items)
     uint8_t* out_u8;
-    int out_u8_w, out_u8_crop; // crop = prepadding * scale
+    int out_u8_w, out_u8_crop, out_u8_bgr; // crop = prepadding * scale; bgr: channel 0 <-> 2 on store
     // work
     const WorkItem* items;
     int nitems;

@@ -277,6 +277,31 @@ def test_fused_conv_last_is_bit_identical_to_postproc_kernel(sr):
         assert (fused == two).all(), (w, h, T, int((fused != two).sum()))
 
 
+def test_bgr_pixel_order(sr, paths):
+    """BGR(A) images (the reference's Windows/WIC path, realsr_preproc.comp:17-21 `bgr` specialisation):
+    processing a channel-swapped image with bgr=1 gives the channel-swapped result, RGB and RGBA, fused and TTA paths."""
+    sr.tilesize = 32
+    t = R.RealSR(0, tta_mode=True)
+    t.load(*paths)
+    t.tilesize = 32
+    try:
+        for eng, (w, h, c) in ((sr, (50, 43, 3)), (sr, (37, 20, 4)), (t, (40, 33, 3))):
+            img = synth.make_image(7 + c, w, h, c)
+            want = eng.process(img)
+            swapped = img.copy()
+            swapped[..., [0, 2]] = img[..., [2, 0]]
+            eng.set_option("bgr", 1)
+            try:
+                got = eng.process(swapped)
+            finally:
+                eng.set_option("bgr", 0)
+            back = got.copy()
+            back[..., [0, 2]] = got[..., [2, 0]]
+            assert (back == want).all(), (w, h, c)
+    finally:
+        t.close()
+
+
 # ---- several GPUs: group creation, tile-row sharding of one image ------------------------------------------------------
 def test_tile_rows_and_group_processing_equal_the_full_image(paths):
     """one large image split by tile rows.  Two contexts (both on GPU 0 here) each process a disjoint range of

@@ -456,6 +456,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             if (tracing) t_arr = __builtin_amdgcn_s_memtime();                                                       \
             if (ITEMQ) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(item_q)::"memory");                   \
             else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
+            if (tracing) t_rel = __builtin_amdgcn_s_memtime();                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             RSR_LDX(0, NXB) if (WDB) { RSR_LDW(WNXT, 0, NDX, NWB) }                                                  \
         }                                                                                                            \
@@ -554,7 +555,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         if (tracing && lane == 0 && t + 1 < 512)                                                                     \
         {                                                                                                            \
             a.trace[2 * (t + 1)] = t_arr;                                                                            \
-            a.trace[2 * (t + 1) + 1] = __builtin_amdgcn_s_memtime();                                                 \
+            a.trace[2 * (t + 1) + 1] = t_rel;                                                                        \
         }                                                                                                            \
         sP = nsP;                                                                                                    \
         sW = nsW;                                                                                                    \
@@ -572,7 +573,8 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         return w;
     };
 
-    unsigned long long t_arr = 0;
+    unsigned long long t_arr = 0, t_rel = 0;
+    (void)t_rel;
     if (tracing) t_arr = __builtin_amdgcn_s_memtime();
     asm volatile("s_barrier" ::: "memory"); // E_0: half-stage 0 is in LDS
     if (tracing && lane == 0)

@@ -9,9 +9,9 @@ make -s -C $D/csrc ../lib/librealsr_hip.so
 mkdir -p $D/lib/exp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden "$@" -c $D/csrc/$FILE.hip -o $D/lib/exp/$NAME.$FILE.o
 OBJS=""
-for o in kernels conv_flow engine capi model; do
+for o in kernels conv_flow engine capi group model; do
   if [ "$o" = "$FILE" ]; then OBJS="$OBJS $D/lib/exp/$NAME.$FILE.o"; else OBJS="$OBJS $D/lib/obj/$o.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/lib/exp/$NAME.so $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/lib/exp/$NAME.so $OBJS -ldl
 rm -f $D/lib/exp/$NAME.$FILE.o
 ls -la $D/lib/exp/$NAME.so

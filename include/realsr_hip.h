@@ -225,7 +225,7 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                       touched last -> Infinity Cache hits); 0: always forwards
  *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
  *                         1 skip LDS-DMA, 2 skip MFMAs (kernels 2/3), 4 skip epilogue stores, 16 generic epilogue everywhere
- *                         (kernels 2/3), 64 direct epilogues (kernels 2/3), 4096 no identity tap, 32768 stream weights even
+ *                         (kernels 2/3), 64 direct epilogues (kernels 2/3), 4096 no identity tap (kernels 1-3), 32768 stream weights even
  *                         when resident (kernel 3) */
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
 

@@ -43,6 +43,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // the compiler move row k+1's writes above row k's read-back (seen on hardware as a run-to-run varying corruption).
 typedef half4 __attribute__((may_alias)) half4_scr;
 typedef u32x4 __attribute__((may_alias)) u32x4_scr;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 __attribute__((may_alias)) f32x4_lds;
 
 namespace {
 
@@ -108,7 +110,7 @@ __device__ __forceinline__ char* uniform_ptr(const void* p)
 } // namespace
 
 // EPI: 0 generic (conv_last: planar fp16 [3][H][W] output)      1 v = act(acc)  -> fp16 planes
-//      2 v = s1*acc [+ r1 unless it sits in the accumulator as an identity tap] [, v = s2*v + r2] -> fp16 planes
+//      2 v = s1*acc (the conv's own input rides in the accumulator as an identity tap) [, v = s2*v + r2] -> fp16 planes
 // NTW: n-tiles (32 output channels) per MFMA wave; the workgroup has 4*NT/NTW MFMA waves + 4 loader waves.
 // DEFER: double-buffered accumulators, block r drained underneath block r+1 (NT == 1 only).
 template <int NT, int NTW, bool UPS, int EPI, bool DEFER>
@@ -251,14 +253,21 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     const int woff = C::W_OFF + (ntw0 * 32 + l32) * 32 + ((hi ^ ((l32 >> 3) & 1)) << 4);
 
     // bias in accumulator layout (lane (px, hi), reg q*4+e -> cout q*8 + hi*4 + e): C operand of a block's first MFMAs
+    // Without the deferred epilogue the registers are re-read from LDS at the end of every epilogue (live only up to the
+    // next block's first step): the 3-waves-per-SIMD workgroup has 168 VGPRs and the epilogue needs them.
     f32x16 bias16[NTW];
+    auto load_bias = [&]() {
 #pragma unroll
-    for (int n = 0; n < NTW; n++)
+        for (int n = 0; n < NTW; n++)
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+            for (int q = 0; q < 4; q++)
+            {
+                const f32x4 b4 = *reinterpret_cast<const f32x4_lds*>(smem + C::BIAS_OFF + ((ntw0 + n) * 32 + q * 8 + hi * 4) * 4);
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                bias16[n][q * 4 + e] = reinterpret_cast<const float*>(smem + C::BIAS_OFF)[(ntw0 + n) * 32 + q * 8 + hi * 4 + e];
+                for (int e = 0; e < 4; e++) bias16[n][q * 4 + e] = b4[e];
+            }
+    };
+    load_bias();
 
     // transpose scratch of this wave: per n-tile two 16-channel plane rows of 32 px x 32 B; write side (accumulator
     // layout) lane (px, hi) owns 8 B at px*32 + ((q&1) ^ f(px))*16 + hi*8 of plane q>>1, f(px) = (px>>2)&1;
@@ -269,8 +278,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     const int scr_r = rpx * 32 + ((rk ^ ((rpx >> 2) & 1)) << 4);
 
     const float slope = a.lrelu ? 0.2f : 1.f;
-    const bool idt = (EPI == 2) && a.res1_in_acc && !(a.dbg & 4096);
-    const bool has1 = (EPI == 2) && a.res1_kind == 1 && !idt;
+    const bool idt = (EPI == 2) && a.res1_in_acc; // a fetched first residual arrives as res2 with s2 = 1 (launch_conv_flow)
     const bool has2 = (EPI == 2) && a.res2_kind == 1;
 #ifdef RSR_FLOW_TRACE // experiment builds only: an s_memtime in the loop forces every lgkmcnt wait to 0 (SMEM returns out of order)
     const bool tracing = a.trace && blockIdx.x == 0 && wave == 0;
@@ -324,27 +332,42 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
         for (int p = 0; p < 2; p++) tq[p] = *reinterpret_cast<const u32x4_scr*>(scr + n * 2048 + p * 1024 + scr_r);
     };
-    // residual stages in the transposed domain (lane = 8 consecutive channels of one pixel): v = t + r1, v = v*s2 + r2
+    // residual stage in the transposed domain (lane = 8 consecutive channels of one pixel): v = v*s2 + r2
+    // The second residual (the RRDB input, every third conv5) is fetched ahead of its use when the registers allow it (one
+    // n-tile per wave) -- rows 0-1 one half-stage before the epilogue, rows 2-3 into the same registers once the
+    // epilogue is through with rows 0-1: four dependent HBM round trips per block otherwise.
+    constexpr bool PRE2 = (EPI == 2) && NTW == 1;
+    u32x4 r2q[PRE2 ? 2 : 1][NTW][2]; // rows 0-1, then rows 2-3
+    // Out-of-image lanes / rows read zeros through the buffer range check, like row_store drops them.
+    auto res2_row = [&](u32x4 (&dst)[2], const OutDesc& o, int rr, int n) {
+        const int y = o.y0 + rr;
+        char* ub = uniform_ptr(const_cast<char*>(plane_ptr(a.res2, o.slot, ntw0 * 2)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, y < o.H ? 0x7ffffff0 : 0, 0x00020000);
+        const unsigned pstride = unsigned(a.res2.plane_stride);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.voff, int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride), 0);
+    };
+    auto res2_prefetch = [&](const WorkItem& w, int row0) { // rows row0, row0 + 1
+        if (!PRE2 || !has2) return;
+        const OutDesc o = make_out(w, true);
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+            for (int n = 0; n < NTW; n++) res2_row(r2q[PRE2 ? rr : 0][n], o, row0 + rr, n);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto row_residual = [&](u32x4 (&tq)[2], const OutDesc& o, int rr, int n) {
-        if (!(has1 || has2)) return;
-        const int y = o.y0 + rr, x = o.x0 + rpx;
-        const bool ok = y < o.H && x < o.W;
-        const long long off = ((long long)y * o.W + x) * kFPx + rk * 16;
+        if (!has2) return;
+        u32x4 r2x[2];
+        if (!PRE2) res2_row(r2x, o, rr, n);
 #pragma unroll
         for (int p = 0; p < 2; p++)
         {
-            half8 r1 = {0, 0, 0, 0, 0, 0, 0, 0}, r2 = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (has1 && ok) r1 = *reinterpret_cast<const half8*>(plane_ptr(a.res1, o.slot, (ntw0 + n) * 2 + p) + off);
-            if (has2 && ok) r2 = *reinterpret_cast<const half8*>(plane_ptr(a.res2, o.slot, (ntw0 + n) * 2 + p) + off);
+            const half8 r2 = __builtin_bit_cast(half8, PRE2 ? r2q[PRE2 ? (rr & 1) : 0][n][p] : r2x[p]);
             half8 v = __builtin_bit_cast(half8, tq[p]);
 #pragma unroll
-            for (int e = 0; e < 8; e++)
-            {
-                float f = (float)v[e];
-                if (has1) f += (float)r1[e];
-                if (has2) f = f * a.s2 + (float)r2[e];
-                v[e] = (_Float16)f;
-            }
+            for (int e = 0; e < 8; e++) v[e] = (_Float16)((float)v[e] * a.s2 + (float)r2[e]);
             tq[p] = __builtin_bit_cast(u32x4, v);
         }
     };
@@ -603,6 +626,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                     if (cp == 0) { RSR_HALF_PLAIN(accA, Wa, Wb, true) }
                     else { RSR_HALF_PLAIN(accA, Wa, Wb, false) }
                     ck = cp + 1;
+                    if (cp + 2 >= nst) res2_prefetch(it, 0);
                     RSR_HALF_PLAIN(accA, Wb, Wa, false)
                 }
                 else
@@ -615,13 +639,32 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- epilogue of block r (the fragments of block r+1's first step are already in registers) ----
-            if (EPI == 0) planar_store(accA, it);
+            // The operands of block r+1's first step and the bias registers are (re)loaded while the last row is converted
+            // -- three of the four accumulator rows are dead by then -- so that their registers are the epilogue's in
+            // between (the block's last step has fetched the same fragments already; that copy simply dies here).
+            auto refill = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                const char* xb = xbase(sP, 0);
+                const char* wb = wbase(sW);
+#pragma unroll
+                for (int q = 0; q < 6; q++) { RSR_LDX(q, xb) }
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) { RSR_LDW(Wa, dy, 0, wb) }
+                load_bias();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (EPI == 0)
+            {
+                planar_store(accA, it);
+                refill();
+            }
             else
             {
                 const OutDesc o = make_out(it, true);
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++)
                 {
+                    if (rr == 3) refill();
 #pragma unroll
                     for (int n = 0; n < NTW; n++) row_to_lds(accA[rr][n], n);
 #pragma unroll
@@ -632,6 +675,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                         if (EPI == 2) row_residual(tq, o, rr, n);
                         row_store(tq, o, rr, n);
                     }
+                    if (EPI == 2 && rr == 1) res2_prefetch(it, 2);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -889,9 +933,19 @@ hipError_t flow_init_device()
 }
 
 // flags: bit 0 = two n-tiles per MFMA wave for the 64-output-channel convs (4 MFMA waves), bit 1 = no deferred epilogue
-bool launch_conv_flow(const ConvArgs& a, int nt, int ncu, int flags, hipStream_t st)
+bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStream_t st)
 {
-    if (a.nitems <= 0) return true;
+    if (a_in.nitems <= 0) return true;
+    ConvArgs a = a_in;
+    if (a.res1_kind == 1 && !a.res1_in_acc)
+    {
+        // a first residual that is not this conv's own input (trunk_conv: fea + trunk) is fetched through the second
+        // residual's slot: fp16(s1*acc)*1 + r rounds exactly like fp16(s1*acc) + r
+        if (a.res2_kind) return false;
+        a.res2 = a.res1;
+        a.res2_kind = 1;
+        a.s2 = 1.f;
+    }
     if (((a.n0 + a.n1) & 1) || !a.wpk16) return false;
     const bool ups = a.lvl_out != a.lvl_in;
     int epi = 0;

@@ -586,7 +586,7 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         a.src1 = rdb_d(bi, 0); a.n1 = 4 * P32;
         a.s1 = 0.2f;
         if (trunk_fp32) { a.res1 = t32; a.res1_kind = 2; a.out32a = t32; }
-        else { a.res1 = xs; a.res1_kind = 1; a.res1_in_acc = !(dbg & 4096); a.res1_coef = 5.f; } // 1/0.2, exact in fp16
+        else { a.res1 = xs; a.res1_kind = 1; a.res1_in_acc = plane_ch() == 16 || !(dbg & 4096); a.res1_coef = 5.f; } // 1/0.2, exact in fp16
         if (bi == 2)
         {
             a.s2 = 0.2f;
@@ -1087,7 +1087,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
             {
                 a.res1 = a.src0;
                 a.res1_kind = 1;
-                a.res1_in_acc = !(dbg & 4096);
+                a.res1_in_acc = kv >= 4 || !(dbg & 4096);
                 a.res1_coef = 1.f / s1;
             }
             if (res)

@@ -78,7 +78,7 @@ def test_conv3x3_layer_matches_oracle(sr, cin, cout, h, w, ups, lrelu):
 @pytest.mark.parametrize("cin,cout,h,w", [(192, 64, 20, 40), (64, 64, 33, 50), (192, 64, 70, 90)])
 def test_residual_epilogues_match_numpy(sr, cin, cout, h, w):
     """The Eltwise / BinaryOp layers behind a Convolution in x4.param, fused into its epilogue: RDB conv5
-    (v = 0.2*conv + x, x4.param:17-18; x rides in the accumulator as an identity tap or is fetched: dbg 4096), every third
+    (v = 0.2*conv + x, x4.param:17-18; x rides in the accumulator as an identity tap, or -- kernel 3, dbg 4096 -- is fetched), every third
     RDB (v = 0.2*v + rrdb_in, x4.param:47) and trunk_conv + global skip (x4.param:994-995).  One extra fp16 rounding of
     the intermediate -> |d| <= 2^-9 |ref| + 2e-3.  num_cu = 8 gives every workgroup several blocks (ring wrap-around)."""
     rng = np.random.default_rng(cin + h)
@@ -91,7 +91,7 @@ def test_residual_epilogues_match_numpy(sr, cin, cout, h, w):
     forms = {"conv5": (0.2, True, None, 1.0, 0.2 * conv + x0), "conv5+rrdb": (0.2, True, res, 0.2, 0.2 * (0.2 * conv + x0) + r),
              "trunk": (1.0, False, res, 1.0, conv + r)}
     try:
-        for kernel, flags, dbg, ncu in ((4, 0, 0, 256), (4, 0, 4096, 256), (4, 1, 0, 256), (4, 0, 0, 8), (4, 1, 0, 8), (3, 0, 0, 256), (2, 0, 64, 256)):
+        for kernel, flags, dbg, ncu in ((4, 0, 0, 256), (4, 1, 0, 256), (4, 0, 0, 8), (4, 1, 0, 8), (3, 0, 0, 256), (3, 0, 4096, 256), (2, 0, 64, 256)):
             for k, v in (("kernel", kernel), ("flow_flags", flags), ("dbg", dbg), ("num_cu", ncu)):
                 sr.set_option(k, v)
             for name, (s1, own, rr, s2, ref) in forms.items():
@@ -187,7 +187,7 @@ def test_kernel_paths_agree(sr, w, h):
         sr.set_option("kernel", 3)
         sr.set_option("dbg", 16)  # round-1 kernels with the generic epilogue everywhere
         ref = sr.net_forward(x).astype(np.float32)
-        for kernel, dbg, flags in [(4, 0, 0), (4, 0, 1), (4, 0, 2), (4, 4096, 0), (3, 0, 0), (3, 4096, 0), (3, 64, 0), (2, 0, 0), (1, 0, 0)]:
+        for kernel, dbg, flags in [(4, 0, 0), (4, 0, 1), (4, 0, 2), (3, 0, 0), (3, 4096, 0), (3, 64, 0), (2, 0, 0), (1, 0, 0)]:
             sr.set_option("kernel", kernel)
             sr.set_option("dbg", dbg)
             sr.set_option("flow_flags", flags)

@@ -82,7 +82,7 @@ def sec_res(sr):
         forms = {"conv5": (0.2, True, None, 1.0, 0.2 * conv + x[:cout].astype(np.float32)),
                  "conv5+rrdb": (0.2, True, res, 0.2, 0.2 * (0.2 * conv + x[:cout].astype(np.float32)) + res.astype(np.float32)),
                  "trunk": (1.0, False, res, 1.0, conv + res.astype(np.float32))}
-        for kern, flags, dbg, ncu in ((3, 0, 0, 256), (4, 0, 0, 256), (4, 0, 4096, 256), (4, 1, 0, 256), (4, 1, 4096, 256), (4, 0, 0, 8), (4, 1, 0, 8)):
+        for kern, flags, dbg, ncu in ((3, 0, 0, 256), (3, 0, 4096, 256), (4, 0, 0, 256), (4, 1, 0, 256), (4, 0, 0, 8), (4, 1, 0, 8)):
             sr.set_option("kernel", kern)
             sr.set_option("flow_flags", flags)
             sr.set_option("dbg", dbg)
@@ -149,6 +149,9 @@ def layer_table(ct, npx):
         g[2] += 2.0 * 9 * cin * cout * npx * (4 ** lvl)
     for name, (n, ms, fl) in groups.items():
         print("      %s x%-3d %8.3f ms  %7.1f TFLOP/s (%4.1f%%)  avg %7.1f us" % (name, n, ms, fl / ms / 1e9, fl / ms / 1e9 / 25, ms / n * 1e3))
+    # conv5 of RDB j of every RRDB (j = 2 also carries the RRDB residual)
+    c5 = [[ct[1 + (3 * b + j) * 5 + 4] for b in range(23)] for j in range(3)]
+    print("      conv5 by RDB position: " + "  ".join("j=%d %.1f us" % (j, 1e3 * sum(v) / len(v)) for j, v in enumerate(c5)))
 
 
 def sec_perf():

@@ -217,7 +217,8 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                       497-515, realsr_preproc.comp:17-21); the network always sees RGB.  Default 0 = RGB(A)
  *   "use_dma"           kernel 1 only: LDS-DMA (1) or register staging (0)
  *   "max_lanes"         rsr_process calls in flight per context (default 4); "chunk_mb": download chunk for pageable
- *                       destinations (default 16)
+ *                       destinations (default 16); "copy_threads": CPU threads per staging copy of a pageable image
+ *                       (default 4; 1 = the calling thread alone)
  *   "num_cu"            persistent grid size (profiling aid)
  *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; kernels 2/3, or a
  *                       -DRSR_FLOW_TRACE build of kernel 4), -1 off

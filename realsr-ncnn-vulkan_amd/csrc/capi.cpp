@@ -375,6 +375,11 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         if (value < 1 || value > 4096) return ctx->e.fail(RSR_E_ARG, "chunk_mb out of range");
         ctx->e.chunk_bytes = size_t(value) << 20;
     }
+    else if (k == "copy_threads")
+    {
+        if (value < 1 || value > 64) return ctx->e.fail(RSR_E_ARG, "copy_threads out of range");
+        ctx->e.copy_threads = int(value);
+    }
     else if (k == "trace_conv")
     {
         ctx->e.trace_conv = int(value);

@@ -23,6 +23,56 @@ int Engine::fail(int code, const std::string& msg)
     return code;
 }
 
+CopyPool::~CopyPool()
+{
+    {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
+    }
+    cv.notify_all();
+    for (std::thread& t : workers) t.join();
+}
+
+void CopyPool::copy(void* dst, const void* src, size_t n, int threads)
+{
+    const size_t kMin = size_t(1) << 20; // pieces below 1 MiB are not worth a hand-off
+    int parts = int(std::min<size_t>(size_t(std::max(threads, 1)), n / kMin));
+    if (parts <= 1)
+    {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    const size_t piece = ((n + parts - 1) / parts + 4095) & ~size_t(4095);
+    int pending = 0;
+    {
+        std::lock_guard<std::mutex> lk(m);
+        while (int(workers.size()) < threads - 1)
+            workers.emplace_back([this]() {
+                std::unique_lock<std::mutex> lk(m);
+                for (;;)
+                {
+                    cv.wait(lk, [this]() { return stop || !q.empty(); });
+                    if (q.empty()) return; // stop
+                    const Job j = q.front();
+                    q.pop_front();
+                    lk.unlock();
+                    std::memcpy(j.dst, j.src, j.n);
+                    lk.lock();
+                    if (--*j.pending == 0) done.notify_all();
+                }
+            });
+        for (size_t off = piece; off < n; off += piece)
+        {
+            q.push_back(Job{static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(piece, n - off), &pending});
+            pending++;
+        }
+    }
+    cv.notify_all();
+    std::memcpy(dst, src, std::min(piece, n));
+    std::unique_lock<std::mutex> lk(m);
+    done.wait(lk, [&]() { return pending == 0; });
+}
+
 Engine::~Engine()
 {
     if (device >= 0) (void)hipSetDevice(device);
@@ -880,7 +930,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     if (!is_pinned_host(in))
     {
         if ((rc = ensure_pinned(L->h_in, L->h_in_bytes, nin)) != RSR_OK) return rc;
-        std::memcpy(L->h_in, in, nin);
+        pool.copy(L->h_in, in, nin, copy_threads);
         src = L->h_in;
     }
     HIP_TRY(hipMemcpyAsync(L->d_in.p, src, nin, hipMemcpyHostToDevice, L->copy));
@@ -957,7 +1007,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
         {
             const size_t k = i - 1, off = k * half, n = std::min(half, nout - off);
             HIP_TRY(hipEventSynchronize(L->ev_chunk[k & 1]));
-            std::memcpy(out + off, static_cast<const char*>(L->h_out) + (k & 1) * half, n);
+            pool.copy(out + off, static_cast<const char*>(L->h_out) + (k & 1) * half, n, copy_threads);
         }
     }
     return RSR_OK;

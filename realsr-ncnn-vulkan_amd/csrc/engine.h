@@ -16,10 +16,12 @@
 #include <hip/hip_runtime.h>
 
 #include <condition_variable>
+#include <deque>
 #include <list>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/realsr_hip.h"
@@ -61,6 +63,26 @@ struct Plan
     void* d_tables = nullptr; // one allocation backing all device tables
 };
 
+// Helper threads for the staging copies of pageable images (pinned chunk <-> the caller's malloc'ed buffer): one core
+// moves ~10 GB/s, a 100 MB output would cost as much as a tenth of the network.  Started on first use.
+struct CopyPool
+{
+    struct Job
+    {
+        char* dst;
+        const char* src;
+        size_t n;
+        int* pending; // under m
+    };
+    std::mutex m;
+    std::condition_variable cv, done;
+    std::deque<Job> q;
+    std::vector<std::thread> workers;
+    bool stop = false;
+    ~CopyPool();
+    void copy(void* dst, const void* src, size_t n, int threads); // returns when all of [dst, dst+n) is written
+};
+
 // one in-flight rsr_process call (host API)
 struct Lane
 {
@@ -95,6 +117,8 @@ struct Engine
     int tail_group_slots = 0; // slots per launch group of the 2x / 4x convs (0 = the whole batch at once), see run_network
     int max_lanes = 4;
     size_t chunk_bytes = size_t(16) << 20; // download chunk for pageable destinations
+    int copy_threads = 4;                  // CPU threads per staging copy (1 = the calling thread alone)
+    CopyPool pool;
     hipStream_t stream = nullptr;          // the compute stream
 
     // model

@@ -194,7 +194,8 @@ def sec_perf():
     out = R.PinnedArray((h * 4, w * 4, 3))
     pin = R.PinnedArray((h, w, 3))
     pin.array[:] = img
-    for name, src, dst in (("pageable", img, None), ("pinned", pin.array, out.array)):
+    page_out = np.empty((h * 4, w * 4, 3), dtype=np.uint8)
+    for name, src, dst in (("pageable", img, page_out), ("pinned", pin.array, out.array)):
         sr.process(src, out=dst)
         t = time.time()
         for _ in range(3):

@@ -3,7 +3,7 @@
 // bmp / tga / gif / psd), plus binary PNM (P5/P6) for raw test data; gray -> RGB and gray+alpha -> RGBA (main.cpp:247-260), so
 // the engine only sees c in {3,4}.  Encode: png (own zlib writer: level-2 deflate is ~5x faster than stb's encoder and the
 // save stage is the throughput limit of a directory run) and jpg at quality 100 through stb_image_write (main.cpp:396-404).
-// webp needs libwebp, which this toolchain does not have: refused with a message, like a failed decode in the reference.
+// webp (decode, lossless encode: webp_image.h) goes through the system's libwebp, bound at run time (webp_dl.h).
 #pragma once
 #include <zlib.h>
 
@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "realsr.h"
+#include "webp_dl.h"
 
 #if defined(__GNUC__)
 #pragma GCC diagnostic push
@@ -88,7 +89,17 @@ inline std::string load_image(const std::string& path, Image& out)
 {
     std::vector<uint8_t> f;
     if (!read_file(path, f)) return "cannot read file";
-    if (is_webp(f)) return "webp decoding is not built in (no libwebp in this toolchain)";
+    if (is_webp(f)) // the reference tries webp first and falls through to stb for everything else (main.cpp:231-242)
+    {
+        int w = 0, h = 0, c = 0;
+        std::string err;
+        uint8_t* px = webpdl::decode(f.data(), f.size(), &w, &h, &c, err);
+        if (!px) return err;
+        out.create(w, h, c);
+        std::memcpy(out.data(), px, size_t(w) * h * c);
+        webpdl::release(px);
+        return "";
+    }
     if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return decode_pnm(f, out);
     int w = 0, h = 0, c = 0;
     if (f.size() > size_t(0x7fffffff)) return "file too large";
@@ -160,12 +171,31 @@ inline std::string save_jpg(const std::string& path, const Image& im)
     return stbi_write_jpg(path.c_str(), im.w, im.h, 3, im.data(), 100) ? "" : "jpg encoder failed";
 }
 
+// lossless webp (webp_image.h:50-98)
+inline std::string save_webp(const std::string& path, const Image& im)
+{
+    uint8_t* enc = nullptr;
+    std::string err;
+    const size_t n = webpdl::encode_lossless(im.data(), im.w, im.h, im.elempack, &enc, err);
+    if (!n) return err;
+    FILE* fp = std::fopen(path.c_str(), "wb");
+    bool ok = fp != nullptr;
+    if (fp)
+    {
+        ok = std::fwrite(enc, 1, n, fp) == n;
+        std::fclose(fp);
+    }
+    webpdl::release(enc);
+    return ok ? "" : "cannot write output file";
+}
+
 inline std::string save_image(const std::string& path, const Image& im)
 {
     const std::string ext = lower_ext(path);
     if (ext == "jpg" || ext == "jpeg") return save_jpg(path, im);
     if (ext == "png") return save_png(path, im);
-    return "no encoder for ." + ext + " (webp needs libwebp, which this toolchain does not have)";
+    if (ext == "webp") return save_webp(path, im);
+    return "no encoder for ." + ext;
 }
 
 } // namespace imgio

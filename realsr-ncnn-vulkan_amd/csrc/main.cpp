@@ -7,8 +7,8 @@
 //     reference re-reads x4.bin per GPU, main.cpp:784-786);
 //   * a single input image with several GPUs is split by tile rows over all of them (rsr_process_group); directories are
 //     dealt image by image from the shared queue exactly like the reference (main.cpp:811-828);
-//   * codecs: stb_image / stb_image_write as in the reference (jpg, png, ... in; png, jpg out) + binary pnm; webp needs
-//     libwebp, which this toolchain lacks;
+//   * codecs: stb_image / stb_image_write as in the reference (jpg, png, ... in; png, jpg out) + binary pnm; webp in / lossless
+//     webp out through the system's libwebp, bound at run time (webp_dl.h) -- without it webp files fail like a broken image;
 //   * "-j l:p:s" accepts a single proc count for several GPUs (the reference insists on one per GPU).
 #include <dirent.h>
 #include <sys/stat.h>
@@ -42,7 +42,7 @@ static void print_usage()
     fprintf(stderr, "  -g gpu-id            gpu device to use (default=0) can be 0,1,2 for multi-gpu\n");
     fprintf(stderr, "  -j load:proc:save    thread count for load/proc/save (default=1:2:2) can be 1:2,2,2:2 for multi-gpu\n");
     fprintf(stderr, "  -x                   enable tta mode\n");
-    fprintf(stderr, "  -f format            output image format (jpg/png, default=ext/png)\n");
+    fprintf(stderr, "  -f format            output image format (jpg/png/webp, default=ext/png)\n");
 }
 
 static std::vector<int> parse_int_list(const char* s)
@@ -244,9 +244,9 @@ int main(int argc, char** argv)
         fprintf(stderr, "invalid format argument\n");
         return -1;
     }
-    if (format == "webp")
+    if (format == "webp" && !webpdl::api().error.empty())
     {
-        fprintf(stderr, "output format webp is not built in (no libwebp in this toolchain)\n");
+        fprintf(stderr, "%s\n", webpdl::api().error.c_str());
         return -1;
     }
 

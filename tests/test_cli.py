@@ -74,7 +74,7 @@ def io_harness(tmp_path_factory):
     exe = d / "t_io"
     lib = os.path.join(ROOT, "realsr-ncnn-vulkan_amd", "lib")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", CSRC, "-o", str(exe), str(src), "-L", lib, "-lrealsr_hip",
-                           "-Wl,-rpath," + lib, "-lz"])
+                           "-Wl,-rpath," + lib, "-lz", "-ldl"])
     return str(exe)
 
 
@@ -107,6 +107,38 @@ def test_pnm_and_unsupported_formats(io_harness, tmp_path):
     (tmp_path / "x.webp").write_bytes(b"RIFF\x10\0\0\0WEBPVP8 " + b"\0" * 16)
     r = subprocess.run([io_harness, str(tmp_path / "x.webp"), str(tmp_path / "o3.png")], capture_output=True)
     assert r.returncode == 1 and b"webp" in r.stderr
+
+
+def test_webp_decode_and_lossless_encode(io_harness, tmp_path):
+    """webp in (lossy, lossless, with alpha) and lossless webp out go through libwebp like the reference's webp_image.h;
+    Pillow (its own bundled libwebp) is the independent decoder / encoder on the other side."""
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import features
+    if not features.check("webp"):
+        pytest.skip("Pillow without webp")
+    import ctypes.util
+    if not (ctypes.util.find_library("webp") or os.environ.get("RSR_LIBWEBP")):
+        pytest.skip("no libwebp at run time")
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:37, 0:51]
+    rgb = np.stack([(xx * 5) % 256, (yy * 7) % 256, (xx * yy) % 256], 2).astype(np.uint8)
+    rgb[10:20, 10:30] = rng.integers(0, 256, (10, 20, 3), dtype=np.uint8)
+    rgba = np.concatenate([rgb, ((xx + yy) * 3 % 256).astype(np.uint8)[:, :, None]], 2)
+    cases = {"lossy": (rgb, dict(quality=80)), "lossless": (rgb, dict(lossless=True)),
+             "lossy_alpha": (rgba, dict(quality=70)), "lossless_alpha": (rgba, dict(lossless=True, exact=True))}
+    for name, (arr, kw) in cases.items():
+        src = tmp_path / (name + ".webp")
+        Image.fromarray(arr).save(src, **kw)
+        want = np.asarray(Image.open(src))
+        out = subprocess.check_output([io_harness, str(src), str(tmp_path / (name + ".png"))]).decode().split()
+        assert [int(v) for v in out] == [want.shape[1], want.shape[0], want.shape[2]], name
+        assert (read_png(tmp_path / (name + ".png")) == want).all(), name
+        if "lossless" in name:
+            assert (want == arr).all()
+    for arr in (rgb, rgba):  # png -> lossless webp (WebPEncodeLosslessRGB / RGBA, webp_image.h:66-85)
+        write_png(tmp_path / "e.png", arr)
+        subprocess.check_call([io_harness, str(tmp_path / "e.png"), str(tmp_path / "e.webp")], stdout=subprocess.DEVNULL)
+        assert (np.asarray(Image.open(tmp_path / "e.webp")) == arr).all()
 
 
 def test_jpg_roundtrip_and_png_features(io_harness, tmp_path):
@@ -165,7 +197,10 @@ def test_cli_flag_validation(tmp_path):
     assert "unknown model dir type" in run_cli("-i", str(png), "-o", out, "-m", "models-foo").stderr
     assert "either file or directory" in run_cli("-i", str(png), "-o", str(tmp_path)).stderr
     assert "no CPU fallback" in run_cli("-i", str(png), "-o", out, "-g", "-1").stderr
-    assert "not built in" in run_cli("-i", str(png), "-o", str(tmp_path / "o.webp")).stderr
+    # webp output needs libwebp at run time; pointing the binding at nothing must fail loudly, before any GPU work
+    r = subprocess.run([CLI, "-i", str(png), "-o", str(tmp_path / "o.webp")], capture_output=True, text=True,
+                       env=dict(os.environ, RSR_LIBWEBP="/nonexistent/libwebp.so"))
+    assert r.returncode != 0 and "needs libwebp.so at run time" in r.stderr
 
 
 @pytest.mark.gpu
@@ -207,7 +242,7 @@ def test_cli_jpg_directory_and_threads(tmp_path, model_dir):
                       'if(!e.empty()) return 1; e = imgio::save_image(v[2], im); return e.empty() ? 0 : 2;}\n')
     lib = os.path.join(ROOT, "realsr-ncnn-vulkan_amd", "lib")
     conv = str(tmp / "t_io")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", CSRC, "-o", conv, str(io_src), "-L", lib, "-lrealsr_hip", "-Wl,-rpath," + lib, "-lz"])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", CSRC, "-o", conv, str(io_src), "-L", lib, "-lrealsr_hip", "-Wl,-rpath," + lib, "-lz", "-ldl"])
     sr = R.RealSR(0)
     sr.load(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
     sr.tilesize = 32
@@ -232,3 +267,34 @@ def test_cli_jpg_directory_and_threads(tmp_path, model_dir):
             subprocess.check_call([conv, str(outd / name), str(tmp / "o.png")])
             d = np.abs(read_png(tmp / "o.png").astype(int) - want[name].astype(int))
             assert d.mean() < 2.5, (name, d.mean())
+
+
+@pytest.mark.gpu
+def test_cli_webp_in_and_out(tmp_path, model_dir):
+    """webp inputs (lossy RGB, lossless RGBA) and -f webp output (lossless, webp_image.h:66-85): the CLI's output decodes
+    -- with Pillow's own libwebp -- to exactly what the library returns for the pixels Pillow decodes from the inputs."""
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import features
+    if not features.check("webp"):
+        pytest.skip("Pillow without webp")
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    outd.mkdir()
+    Image.fromarray(synth.make_image(81, 44, 31)).save(ind / "a.webp", quality=85)
+    Image.fromarray(synth.make_image(82, 29, 40, 4)).save(ind / "b.webp", lossless=True, exact=True)
+    sr = R.RealSR(0)
+    sr.load(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
+    sr.tilesize = 32
+    want = {n: sr.process(np.asarray(Image.open(ind / (n + ".webp")))) for n in ("a", "b")}
+    sr.close()
+    r = run_cli("-i", str(ind), "-o", str(outd), "-m", model_dir, "-t", "32", "-f", "webp")
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(outd)) == ["a.webp", "b.webp"]
+    for n in ("a", "b"):
+        got = np.asarray(Image.open(outd / (n + ".webp")))
+        assert got.shape == want[n].shape, n
+        if got.shape[2] == 4:  # WebPEncodeLosslessRGBA is not "exact": colour under alpha == 0 is the encoder's to choose
+            vis = want[n][:, :, 3] > 0
+            assert (got[:, :, 3] == want[n][:, :, 3]).all() and (got[vis] == want[n][vis]).all(), n
+        else:
+            assert (got == want[n]).all(), n

@@ -83,6 +83,10 @@ int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void
 void* rsr_host_alloc(size_t bytes);
 void rsr_host_free(void* p);
 
+/* Free / total device memory of HIP device `gpuid` in MiB: what ncnn's VulkanDevice::get_heap_budget() is to the
+ * reference's automatic tile-size policy (main.cpp:761-774). */
+int rsr_device_memory(int gpuid, long long* free_mb, long long* total_mb);
+
 /* The reference prints one line per tile to stderr (realsr.cpp:481).  Here all tiles of a batch run together: `cb` is
  * called (from the calling thread, kernels enqueued but not necessarily finished) after each tile batch. */
 int rsr_set_progress_callback(rsr_ctx* ctx, void (*cb)(int tiles_done, int tiles_total, void* user), void* user);

@@ -25,7 +25,7 @@ EXPORTS = [
     "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times", "rsr_get_trace",
     "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_model_pack_ex", "rsr_host_alloc", "rsr_host_free",
     "rsr_set_progress_callback", "rsr_conv3x3_res", "rsr_create_group", "rsr_group_transport", "rsr_process_rows",
-    "rsr_process_group",
+    "rsr_process_group", "rsr_device_memory",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -84,6 +84,7 @@ def lib():
     L.rsr_process_device.argtypes = [vp, vp, ip, ip, ip, vp, vp]
     L.rsr_model_pack.argtypes = [cp, cp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rsr_model_pack_ex.argtypes = [cp, cp, vp, C.c_size_t, C.POINTER(C.c_size_t), ip]
+    L.rsr_device_memory.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.rsr_host_alloc.argtypes = [C.c_size_t]
     L.rsr_host_alloc.restype = vp
     L.rsr_host_free.argtypes = [vp]
@@ -336,6 +337,15 @@ class RealSR:
         p = Profile()
         self._ck(self._L.rsr_get_profile(self._h, C.byref(p), int(bool(reset))))
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+def device_memory(gpuid=0):
+    """(free MiB, total MiB) of HIP device gpuid (rsr_device_memory)."""
+    f, t = C.c_longlong(0), C.c_longlong(0)
+    rc = lib().rsr_device_memory(int(gpuid), C.byref(f), C.byref(t))
+    if rc != RSR_OK:
+        raise RealSRError(rc, lib().rsr_last_error(None).decode())
+    return f.value, t.value
 
 
 def create_group(gpuids, parampath, modelpath, tta_mode=False):

@@ -52,6 +52,22 @@ void rsr_host_free(void* p)
     if (p) (void)hipHostFree(p);
 }
 
+int rsr_device_memory(int gpuid, long long* free_mb, long long* total_mb)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || gpuid < 0 || gpuid >= n) return Engine::fail(RSR_E_DEVICE, "invalid gpu device " + std::to_string(gpuid));
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    size_t f = 0, t = 0;
+    hipError_t e = hipSetDevice(gpuid);
+    if (e == hipSuccess) e = hipMemGetInfo(&f, &t);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return Engine::fail(RSR_E_DEVICE, std::string("hipMemGetInfo: ") + hipGetErrorString(e));
+    if (free_mb) *free_mb = (long long)(f >> 20);
+    if (total_mb) *total_mb = (long long)(t >> 20);
+    return RSR_OK;
+}
+
 int rsr_set_progress_callback(rsr_ctx* ctx, void (*cb)(int done, int total, void* user), void* user)
 {
     if (!ctx) return RSR_E_ARG;

@@ -299,8 +299,18 @@ int main(int argc, char** argv)
 
     if (jobs_proc.empty()) jobs_proc.assign(size_t(ngpu), 2);
     if (tilesize.empty()) tilesize.assign(size_t(ngpu), 0);
-    for (int& t : tilesize)
-        if (t == 0) t = 200; // reference policy: heap budget > 1900 MB -> 200 (main.cpp:766-767); an MI355X always qualifies
+    for (size_t i = 0; i < tilesize.size(); i++)
+    {
+        if (tilesize[i] != 0) continue;
+        // the reference's policy on the device's free memory in MB (main.cpp:761-774); an idle MI355X always lands on 200
+        long long budget = 0;
+        if (rsr_device_memory(gpuid[i], &budget, nullptr) != RSR_OK)
+        {
+            fprintf(stderr, "%s\n", rsr_last_error(nullptr));
+            return -1;
+        }
+        tilesize[i] = budget > 1900 ? 200 : budget > 550 ? 100 : budget > 190 ? 64 : 32;
+    }
 
     // one context per GPU: parsed + packed once, one RCCL broadcast (rsr_create_group)
     std::vector<rsr_ctx*> ctxs(size_t(ngpu), nullptr);

@@ -373,3 +373,13 @@ def test_bench_multirank_control_flow_on_one_gpu(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_device_memory_query_feeds_the_tile_policy():
+    """rsr_device_memory = the heap budget behind the CLI's automatic tile size (main.cpp:761-774): an MI355X reports its
+    288 GB, far above the 1900 MB that selects tile 200; a device that does not exist is an error, not a crash."""
+    free_mb, total_mb = R.device_memory(0)
+    assert total_mb > 200 * 1024 and 1900 < free_mb <= total_mb
+    with pytest.raises(R.RealSRError):
+        R.device_memory(97)

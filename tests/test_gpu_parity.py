@@ -231,6 +231,26 @@ def test_process_matches_oracle_within_one(sr, sr_tta, oracle_net, w, h, c, T, t
     assert (d > 0).mean() < 0.15  # +-1 is the bar; ~3-6 % of the bytes sit on a rounding boundary
 
 
+def test_process_matches_oracle_on_seeded_random_geometries(sr, sr_tta, oracle_net):
+    """A seeded sweep over image sizes, channel counts, tile sizes that divide nothing and TTA: ragged last tiles in both
+    directions, single-row / single-column images, tiles larger than the image -- same +-1 bar as above."""
+    rng = np.random.default_rng(20240923)
+    cases = [(1, 1, 3, 32, False), (1, 47, 3, 33, False), (61, 1, 4, 35, True)]
+    for _ in range(9):
+        tta = bool(rng.integers(0, 4) == 0)
+        lim = 40 if tta else 90
+        cases.append((int(rng.integers(2, lim)), int(rng.integers(2, lim)), int(rng.choice([3, 4])), int(rng.integers(32, 71)), tta))
+    for w, h, c, T, tta in cases:
+        eng = sr_tta if tta else sr
+        eng.tilesize = T
+        img = synth.make_image(1000 + w * 97 + h, w, h, c)
+        ref = oracle_net.process(img, T, tta=tta)
+        got = eng.process(img)
+        assert got.shape == ref.shape == (4 * h, 4 * w, c)
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() <= 1, ((w, h, c, T, tta), int(d.max()), np.argwhere(d > 1)[:4])
+
+
 def test_golden_fixtures(sr, sr_tta):
     g = np.load(os.path.join(HERE, "golden", "cases.npz"))
     names = sorted(k[:-4] for k in g.files if k.endswith("_cfg"))

@@ -686,11 +686,13 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     else
     {
         // ---- deferred epilogue (32 output channels, 4 MFMA waves): block r accumulates into one accumulator set while
-        // the other set, holding block r-1, is drained during block r's first five steps.  The work is cut into pieces
-        // of ~5 instructions that ride behind individual MFMA cells (fenced in place): step k converts row k (per value
-        // pair: LeakyReLU = med3(v, slope*v, +inf), fp16 pack; per quad one ds_write_b64 into the transpose scratch),
-        // step k+1 reads the row back transposed (2 ds_read_b128) and stores it (2 x 1 KiB).  The first block drains
-        // its uninitialised partner set into a null resource.
+        // the other set, holding block r-1, is drained during block r's first ten steps.  The work is cut into 60 pieces
+        // of <= 5 instructions that ride behind every second MFMA cell (fenced in place; generated by
+        // tools/gen_flow_hooks.py): per row eight conversions of a value pair (LeakyReLU = med3(v, slope*v, +inf), fp16
+        // pack), four ds_write_b64 into the transpose scratch, one read-back (2 ds_read_b128) and, three pieces later, the
+        // two 1-KiB stores.  ~2.5 VALU instructions per 32-cycle MFMA slot: the matrix pipe does not notice (at one piece per
+        // cell -- the drain squeezed into five steps -- a block's first two half-stages ran 30-50 % long).  The first block
+        // drains its uninitialised partner set into a null resource.
         OutDesc od = make_out(it, false);
         u32x4 tq[2];
         half2v pk[4][2];
@@ -702,78 +704,149 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(p) * unsigned(a.out16.plane_stride)), 0, 0);
         };
+// GENERATED-HOOKS-BEGIN (tools/gen_flow_hooks.py)
 #define RSR_HK_S0(c) RSR_HK_S0_##c
 #define RSR_HK_S0_0 __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][0], v1_ = RSR_OLD[0][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][2], v1_ = RSR_OLD[0][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][4], v1_ = RSR_OLD[0][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][6], v1_ = RSR_OLD[0][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][8], v1_ = RSR_OLD[0][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][10], v1_ = RSR_OLD[0][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[0][0][12], v1_ = RSR_OLD[0][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][14], v1_ = RSR_OLD[0][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][2], v1_ = RSR_OLD[0][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][4], v1_ = RSR_OLD[0][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][6], v1_ = RSR_OLD[0][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S0_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_11 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S0_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S1(c) RSR_HK_S1_##c
-#define RSR_HK_S1_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][0], v1_ = RSR_OLD[1][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][2], v1_ = RSR_OLD[1][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][4], v1_ = RSR_OLD[1][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][6], v1_ = RSR_OLD[1][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][8], v1_ = RSR_OLD[1][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][10], v1_ = RSR_OLD[1][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[1][0][12], v1_ = RSR_OLD[1][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][14], v1_ = RSR_OLD[1][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 0, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 0, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][8], v1_ = RSR_OLD[0][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][10], v1_ = RSR_OLD[0][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][12], v1_ = RSR_OLD[0][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][14], v1_ = RSR_OLD[0][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S1_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S2(c) RSR_HK_S2_##c
-#define RSR_HK_S2_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][0], v1_ = RSR_OLD[2][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][2], v1_ = RSR_OLD[2][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][4], v1_ = RSR_OLD[2][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][6], v1_ = RSR_OLD[2][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][8], v1_ = RSR_OLD[2][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][10], v1_ = RSR_OLD[2][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[2][0][12], v1_ = RSR_OLD[2][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][14], v1_ = RSR_OLD[2][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 1, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 1, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_1 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][0], v1_ = RSR_OLD[1][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_5 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][2], v1_ = RSR_OLD[1][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_9 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 0, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S2_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 0, 1); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S3(c) RSR_HK_S3_##c
-#define RSR_HK_S3_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][0], v1_ = RSR_OLD[3][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_2 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][2], v1_ = RSR_OLD[3][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_3 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][4], v1_ = RSR_OLD[3][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_4 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][6], v1_ = RSR_OLD[3][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][8], v1_ = RSR_OLD[3][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_6 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][10], v1_ = RSR_OLD[3][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } { float v0_ = RSR_OLD[3][0][12], v1_ = RSR_OLD[3][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_8 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][14], v1_ = RSR_OLD[3][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_9 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 2, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 2, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][4], v1_ = RSR_OLD[1][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][6], v1_ = RSR_OLD[1][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][8], v1_ = RSR_OLD[1][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][10], v1_ = RSR_OLD[1][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S3_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S4(c) RSR_HK_S4_##c
-#define RSR_HK_S4_0 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_1 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][12], v1_ = RSR_OLD[1][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S4_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_3 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][14], v1_ = RSR_OLD[1][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S4_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_5 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S4_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_7 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_7 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
 #define RSR_HK_S4_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_9 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_10 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 3, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 3, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][0], v1_ = RSR_OLD[2][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S4_11 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][2], v1_ = RSR_OLD[2][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5(c) RSR_HK_S5_##c
+#define RSR_HK_S5_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_1 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_3 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 1, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_5 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 1, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][4], v1_ = RSR_OLD[2][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][6], v1_ = RSR_OLD[2][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S5_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6(c) RSR_HK_S6_##c
+#define RSR_HK_S6_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][8], v1_ = RSR_OLD[2][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][10], v1_ = RSR_OLD[2][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][12], v1_ = RSR_OLD[2][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][14], v1_ = RSR_OLD[2][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S6_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7(c) RSR_HK_S7_##c
+#define RSR_HK_S7_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_1 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][0], v1_ = RSR_OLD[3][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_5 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][2], v1_ = RSR_OLD[3][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_9 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 2, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S7_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 2, 1); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8(c) RSR_HK_S8_##c
+#define RSR_HK_S8_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][4], v1_ = RSR_OLD[3][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][6], v1_ = RSR_OLD[3][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][8], v1_ = RSR_OLD[3][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][10], v1_ = RSR_OLD[3][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S8_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9(c) RSR_HK_S9_##c
+#define RSR_HK_S9_0 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][12], v1_ = RSR_OLD[3][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_2 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][14], v1_ = RSR_OLD[3][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_4 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_6 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_7 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_8 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_9 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 3, 0); } __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_10 __builtin_amdgcn_sched_barrier(0);
+#define RSR_HK_S9_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 3, 1); } __builtin_amdgcn_sched_barrier(0);
+// GENERATED-HOOKS-END
 #define RSR_BLOCK(ACC)                                                                                               \
     {                                                                                                                \
         ck = 0;                                                                                                      \
         RSR_HALF(ACC, Wa, Wb, true, RSR_HK_S0, 0, RSR_HK_S1, 0, RSR_HK_S2, 0)                                        \
         ck = 1;                                                                                                      \
-        RSR_HALF(ACC, Wb, Wa, false, RSR_HK_S3, 0, RSR_HK_S4, 0, RSR_NOHK, 1)                                        \
-        for (int cp = 2; cp < nst; cp += 2)                                                                          \
+        RSR_HALF(ACC, Wb, Wa, false, RSR_HK_S3, 0, RSR_HK_S4, 0, RSR_HK_S5, 0)                                       \
+        ck = 2;                                                                                                      \
+        RSR_HALF(ACC, Wa, Wb, false, RSR_HK_S6, 0, RSR_HK_S7, 0, RSR_HK_S8, 0)                                       \
+        ck = 3;                                                                                                      \
+        RSR_HALF(ACC, Wb, Wa, false, RSR_HK_S9, 0, RSR_NOHK, 1, RSR_NOHK, 1)                                         \
+        for (int cp = 4; cp < nst; cp += 2)                                                                          \
         {                                                                                                            \
             ck = cp;                                                                                                 \
             RSR_HALF_PLAIN(ACC, Wa, Wb, false)                                                                       \
@@ -821,6 +894,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             }
         }
 #undef RSR_BLOCK
+// GENERATED-UNDEFS-BEGIN (tools/gen_flow_hooks.py)
 #undef RSR_HK_S0
 #undef RSR_HK_S0_0
 #undef RSR_HK_S0_1
@@ -886,6 +960,72 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #undef RSR_HK_S4_9
 #undef RSR_HK_S4_10
 #undef RSR_HK_S4_11
+#undef RSR_HK_S5
+#undef RSR_HK_S5_0
+#undef RSR_HK_S5_1
+#undef RSR_HK_S5_2
+#undef RSR_HK_S5_3
+#undef RSR_HK_S5_4
+#undef RSR_HK_S5_5
+#undef RSR_HK_S5_6
+#undef RSR_HK_S5_7
+#undef RSR_HK_S5_8
+#undef RSR_HK_S5_9
+#undef RSR_HK_S5_10
+#undef RSR_HK_S5_11
+#undef RSR_HK_S6
+#undef RSR_HK_S6_0
+#undef RSR_HK_S6_1
+#undef RSR_HK_S6_2
+#undef RSR_HK_S6_3
+#undef RSR_HK_S6_4
+#undef RSR_HK_S6_5
+#undef RSR_HK_S6_6
+#undef RSR_HK_S6_7
+#undef RSR_HK_S6_8
+#undef RSR_HK_S6_9
+#undef RSR_HK_S6_10
+#undef RSR_HK_S6_11
+#undef RSR_HK_S7
+#undef RSR_HK_S7_0
+#undef RSR_HK_S7_1
+#undef RSR_HK_S7_2
+#undef RSR_HK_S7_3
+#undef RSR_HK_S7_4
+#undef RSR_HK_S7_5
+#undef RSR_HK_S7_6
+#undef RSR_HK_S7_7
+#undef RSR_HK_S7_8
+#undef RSR_HK_S7_9
+#undef RSR_HK_S7_10
+#undef RSR_HK_S7_11
+#undef RSR_HK_S8
+#undef RSR_HK_S8_0
+#undef RSR_HK_S8_1
+#undef RSR_HK_S8_2
+#undef RSR_HK_S8_3
+#undef RSR_HK_S8_4
+#undef RSR_HK_S8_5
+#undef RSR_HK_S8_6
+#undef RSR_HK_S8_7
+#undef RSR_HK_S8_8
+#undef RSR_HK_S8_9
+#undef RSR_HK_S8_10
+#undef RSR_HK_S8_11
+#undef RSR_HK_S9
+#undef RSR_HK_S9_0
+#undef RSR_HK_S9_1
+#undef RSR_HK_S9_2
+#undef RSR_HK_S9_3
+#undef RSR_HK_S9_4
+#undef RSR_HK_S9_5
+#undef RSR_HK_S9_6
+#undef RSR_HK_S9_7
+#undef RSR_HK_S9_8
+#undef RSR_HK_S9_9
+#undef RSR_HK_S9_10
+#undef RSR_HK_S9_11
+// GENERATED-UNDEFS-END
     }
 #undef RSR_HALF_PLAIN
 #undef RSR_HALF

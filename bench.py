@@ -110,6 +110,31 @@ def cpu_baseline(pp, bp):
     return res
 
 
+def board_gemm_ceiling(dev):
+    """The vendor fp16 GEMM (torch.mm -> hipBLASLt / rocBLAS) on N(0,1) and on all-zero operands, same board, same moment:
+    what the 1,400 W cap leaves of the 2.5 PFLOP/s peak for full-entropy data -- the practical MFMA ceiling next to
+    which roofline.frac should be read.  ~0.5 s of GPU time, outside the timed region."""
+    n, iters, out = 8192, 20, {}
+    a = torch.empty((n, n), dtype=torch.float16, device=dev)
+    b = torch.empty((n, n), dtype=torch.float16, device=dev)
+    for fill in ("zeros", "randn"):
+        if fill == "randn":
+            a.normal_()
+            b.normal_()
+        else:
+            a.zero_()
+            b.zero_()
+        for _ in range(3):
+            torch.mm(a, b)
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(iters):
+            torch.mm(a, b)
+        torch.cuda.synchronize()
+        out[fill] = 2.0 * n ** 3 * iters / (time.time() - t) / 1e12
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,6 +341,14 @@ def main():
                 "timing": "hipEvents on the launch stream around every kernel of the timed steps (rank 0), inside the timed region",
                 "note": "the board sits at its 1400 W cap during this workload (sclk ~1.75 GHz of 2.4): at that clock the MFMA peak is ~1.8 PFLOP/s",
             }
+            try:
+                g = board_gemm_ceiling(dev)
+                res["roofline"]["vendor_gemm_same_board"] = {
+                    "what": "torch.mm fp16 8192^3 (hipBLASLt/rocBLAS), measured right after the timed region",
+                    "randn_tflops": round(g["randn"], 1), "zeros_tflops": round(g["zeros"], 1),
+                    "achieved_over_randn_gemm": round(ach / g["randn"], 4), "all_convs_over_randn_gemm": round(ach_all / g["randn"], 4)}
+            except Exception as e:  # noqa: BLE001 -- context only, never fail the bench on it
+                res["roofline"]["vendor_gemm_same_board"] = {"what": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(pp, bp)

@@ -27,10 +27,6 @@
 // loaders' vmcnt bookkeeping nor need LDS), so a launch never has to be split.
 #include "kernels.h"
 
-#ifndef RSR_EXP
-#define RSR_EXP 0 // experiment switch of variant builds (tools/build_variant.sh); 0 in the product
-#endif
-
 namespace rsr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

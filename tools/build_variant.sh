@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build an experimental variant of librealsr_hip.so:  tools/build_variant.sh NAME FILE "-DRSR_EXP=1 ..."
+# Build an experimental variant of librealsr_hip.so:  tools/build_variant.sh NAME FILE "-DRSR_FLOW_TRACE ..."
 # FILE = kernels | conv_flow.  -> realsr-ncnn-vulkan_amd/lib/exp/NAME.so   (load with RSR_LIB=<path>; lib/ is git-ignored
 # but travels to the GPU box)
 set -e

@@ -449,8 +449,12 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         WS[DY][n_], X[(RR) + (DY)], ((FIRST) && (DY) == 0) ? bias16[n_] : ACC[RR][n_], 0, 0, 0);
 #define RSR_NOHK(c)
 
-    // One (dx) step = 12 cells (dy, rr) in anti-diagonal order; the fragments of the NEXT step (NXB / NWB: their LDS
-    // bases, NDX its dx) are reloaded in place as soon as the diagonal that last reads them has been issued.  BAR: the
+    // One (dx) step = 12 cells (dy, rr): rows 0-1 through the three dy taps, then rows 2-3 -- (0,0) (0,1) (1,0) (1,1) (2,0)
+    // (2,1) | (0,2) (0,3) (1,2) (1,3) (2,2) (2,3).  Consecutive MFMAs share the weight fragment in pairs and the pixel
+    // fragment along the short diagonals (14 operand changes per step; 18 in plain anti-diagonal order), a row's
+    // accumulator comes back every second MFMA, and fragment X[j] is dead after cells 0 / 2 / 6 / 8 / 10 / 11: the
+    // fragments of the NEXT step (NXB / NWB: their LDS bases, NDX its dx) are reloaded in place right there, >= 8 MFMA
+    // slots before their first use.  BAR: the
     // dx = 2 step of a half-stage -- once the first three cells are issued every LDS read of the half-stage has had > 100
     // cycles to return, the wave passes the barrier ("my reads of this half-stage are done" / "the next one has landed")
     // and only then touches the next half-stage's slots.  WCUR / WNXT: weight fragment sets (the same array when !WDB).
@@ -480,11 +484,13 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             RSR_LDX(0, NXB) if (WDB) { RSR_LDW(WNXT, 0, NDX, NWB) }                                                  \
         }                                                                                                            \
         RSR_LDX(1, NXB) if (WDB) { RSR_LDW(WNXT, 1, NDX, NWB) }                                                      \
-        RSR_CELL(ACC, WCUR, 0, 2, FIRST) HK(3) RSR_CELL(ACC, WCUR, 1, 1, FIRST) HK(4) RSR_CELL(ACC, WCUR, 2, 0, FIRST) HK(5) \
-        RSR_LDX(2, NXB) if (WDB) { RSR_LDW(WNXT, 2, NDX, NWB) }                                                      \
-        RSR_CELL(ACC, WCUR, 0, 3, FIRST) HK(6)                                                                       \
+        RSR_CELL(ACC, WCUR, 1, 1, FIRST) HK(3) RSR_CELL(ACC, WCUR, 2, 0, FIRST) HK(4) RSR_CELL(ACC, WCUR, 2, 1, FIRST) HK(5) \
+        if (WDB) { RSR_LDW(WNXT, 2, NDX, NWB) }                                                                      \
+        RSR_CELL(ACC, WCUR, 0, 2, FIRST) HK(6)                                                                       \
+        RSR_LDX(2, NXB)                                                                                              \
+        RSR_CELL(ACC, WCUR, 0, 3, FIRST) HK(7)                                                                       \
         if (!WDB) { RSR_LDW(WNXT, 0, NDX, NWB) }                                                                     \
-        RSR_CELL(ACC, WCUR, 1, 2, FIRST) HK(7) RSR_CELL(ACC, WCUR, 2, 1, FIRST) HK(8)                                \
+        RSR_CELL(ACC, WCUR, 1, 2, FIRST) HK(8)                                                                       \
         RSR_LDX(3, NXB)                                                                                              \
         RSR_CELL(ACC, WCUR, 1, 3, FIRST) HK(9)                                                                       \
         if (!WDB) { RSR_LDW(WNXT, 1, NDX, NWB) }                                                                     \
@@ -502,24 +508,27 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         if (BAR)                                                                                                     \
         {                                                                                                            \
             RSR_SG(RSR_DSR, WDB ? 4 : 2);                                                                            \
-            RSR_SG(RSR_MFMA, 3 * NTW); RSR_SG(RSR_DSR, WDB ? 2 : 1);                                                 \
+            RSR_SG(RSR_MFMA, 3 * NTW);                                                                               \
         }                                                                                                            \
         else                                                                                                         \
         {                                                                                                            \
             RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, WDB ? 2 : 1);                                                 \
             RSR_SG(RSR_MFMA, 2 * NTW); RSR_SG(RSR_DSR, WDB ? 2 : 1);                                                 \
-            RSR_SG(RSR_MFMA, 3 * NTW); RSR_SG(RSR_DSR, WDB ? 2 : 1);                                                 \
+            RSR_SG(RSR_MFMA, 3 * NTW);                                                                               \
         }                                                                                                            \
         if (WDB)                                                                                                     \
         {                                                                                                            \
-            RSR_SG(RSR_MFMA, 3); RSR_SG(RSR_DSR, 1);                                                                 \
+            RSR_SG(RSR_DSR, 1);                                                                                      \
+            RSR_SG(RSR_MFMA, 1); RSR_SG(RSR_DSR, 1);                                                                 \
+            RSR_SG(RSR_MFMA, 2); RSR_SG(RSR_DSR, 1);                                                                 \
             RSR_SG(RSR_MFMA, 2); RSR_SG(RSR_DSR, 1);                                                                 \
             RSR_SG(RSR_MFMA, 1); RSR_SG(RSR_DSR, 1);                                                                 \
         }                                                                                                            \
         else                                                                                                         \
         {                                                                                                            \
+            RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, 1);                                                           \
             RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, NTW);                                                         \
-            RSR_SG(RSR_MFMA, 2 * NTW); RSR_SG(RSR_DSR, 1);                                                           \
+            RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, 1);                                                           \
             RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, NTW);                                                         \
             RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, 1);                                                           \
             RSR_SG(RSR_MFMA, 1 * NTW); RSR_SG(RSR_DSR, 1 + NTW);                                                     \

@@ -263,6 +263,24 @@ def main():
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             host[name] = float(tt.item())
         host["identical_to_device_path"] = bool((torch.from_numpy(pin_out.array[::97, ::89].copy()).to(torch.int64).sum().item()) == checksum)
+        # two caller threads on the one context (the reference's jobs_proc = 2, main.cpp:811-828): upload of frame k+1 and
+        # download of frame k-1 ride under the kernels of frame k
+        if world == 1:
+            import threading
+            pin_out2 = R.PinnedArray((H_IN * SCALE, W_IN * SCALE, 3))
+
+            def worker(dst):
+                for _ in range(args.steps):
+                    sr.process(pin_in.array, out=dst, push_params=False)
+
+            ths = [threading.Thread(target=worker, args=(o.array,)) for o in (pin_out, pin_out2)]
+            t1 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            host["pinned_2threads"] = (time.perf_counter() - t1) / 2
+            pin_out2.free()
         pin_in.free()
         pin_out.free()
 
@@ -304,6 +322,10 @@ def main():
                              "buffers": "malloc'd: staged through the call's pinned lane, download in 16 MB chunks"},
                 "unit": "Mpix/s", "bytes_identical_to_device_path": host["identical_to_device_path"],
             }
+            if "pinned_2threads" in host:
+                res["host_to_host"]["pinned_2_caller_threads"] = {
+                    "value": round(out_mpix * args.steps / host["pinned_2threads"], 3), "ms_per_step": round(host["pinned_2threads"] / args.steps * 1e3, 3),
+                    "what": "two threads calling rsr_process on the one context (jobs_proc = 2): transfers of neighbouring frames overlap the kernels"}
         if prof and prof["conv_ms"] > 0:
             # Dominant kernel class: the 276 dense-block convs cin in {64,96,128,160} -> 32 (conv indices 1+5j+k, k<4),
             # ~50 % of the frame, all launches of ONE kernel: rsr::conv3x3_flow<1,1,false,1,true>.  Its launches are bracketed

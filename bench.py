@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- RealSR x4 tiled inference on MI355X: BASELINE.json's metric on its config C2.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+        N = 1: runs in this process.  N > 1 without a torch.distributed environment: this script launches the N ranks
+        itself (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...) and refuses to
+        report anything but n_gpus == N.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          # the driver's own launch: WORLD_SIZE must equal N
+    python bench.py --mode group --gpus N --frames F    # the PRODUCT's multi-GPU path in ONE process (config C4):
+        rsr_create_group (weights by one RCCL broadcast) + jobs_proc threads per GPU on one shared frame queue
 
 A "step" = one pass of the hot path (preproc -> 351 fused convs -> postproc over all 60 tiles) over one synthetic
 1920x1080 RGB frame per GPU.  One process per GPU; the only collective is the broadcast of the packed weights (RCCL) at
 load.  Weak scaling: every rank upsamples its own frame each step; value = total output Mpix / max-rank time.
 
 `value` is the HBM-resident rate (input and output images in device memory when the timed region starts -- the driver
-contract).  SURVEY.md 8(d) defines the end-user metric as host memory -> host memory: that run (rsr_process, the
-reference's RealSR::process boundary, H2D + network + D2H) is timed right behind it and reported in `host_to_host`
-(pinned buffers = what the CLI uses; pageable = a caller that hands over malloc'd memory).
+contract: a PCIe-inclusive rate is never `value`).  SURVEY.md 8(d) defines the end-user metric as host memory -> host
+memory: that run (rsr_process, the reference's RealSR::process boundary, H2D + network + D2H) is timed right behind it and
+reported in `host_to_host` (pinned buffers = what the CLI uses; pageable = a caller that hands over malloc'd memory).
 
 Prints ONE JSON line (rank 0).  The CPU oracle is used only for the cpu_baseline leg.
 """
@@ -20,20 +25,16 @@ import argparse
 import json
 import os
 import re
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import realsr_ncnn_vulkan_amd as R  # noqa: E402
-from realsr_ncnn_vulkan_amd import synth  # noqa: E402
 
 W_IN, H_IN, TILE, PREPAD, SCALE = 1920, 1080, 200, 10, 4
 FLOP_PER_PADDED_LR_PX = 35853696  # 2 x 17,926,848 MAC
@@ -49,17 +50,28 @@ def padded_px(w, h, T, P):
     return n
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the tracked rocprofv3 PMC summary (tools/gpu_round.sh writes it:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md).  None when the file is not there."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.txt")
-    try:
-        txt = open(path).read()
-    except OSError:
-        return None, None
-    m = re.search(r"^dominant\s+\S.*?bytes_per_launch=([0-9.eE+]+)", txt, re.M)
-    return (float(m.group(1)), "profiles/r02_pmc_traffic.txt") if m else (None, None)
+    """HBM bytes per launch of the dominant kernel from the newest tracked rocprofv3 PMC summary (tools/gpu_round.sh writes
+    it: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md).  None when no such file is there."""
+    for name in ("r03_pmc_traffic.txt", "r02_pmc_traffic.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            txt = open(path).read()
+        except OSError:
+            continue
+        m = re.search(r"^dominant\s+\S.*?bytes_per_launch=([0-9.eE+]+)", txt, re.M)
+        if m:
+            return float(m.group(1)), "profiles/" + name
+    return None, None
 
 
 def cpu_baseline(pp, bp):
@@ -67,7 +79,10 @@ def cpu_baseline(pp, bp):
     (1) the oracle, 16 OpenMP threads, one padded 220x220 tile of the C2 frame; (2) the oracle single-threaded on one
     84x84 padded tile (C1's code path; C1's four 148x148 tiles are 12.4x that); (3) PyTorch-CPU
     (oneDNN) on the 220x220 tile, an independent construction of the same graph."""
+    import numpy as np
+    import torch
     import oracle
+    from realsr_ncnn_vulkan_amd import synth
     net = oracle.OracleNet(pp, bp)
     img = synth.make_image(1234, 200, 200)
     net.process(synth.make_image(1, 24, 24), 200)  # warm the thread pool
@@ -114,6 +129,7 @@ def board_gemm_ceiling(dev):
     """The vendor fp16 GEMM (torch.mm -> hipBLASLt / rocBLAS) on N(0,1) and on all-zero operands, same board, same moment:
     what the 1,400 W cap leaves of the 2.5 PFLOP/s peak for full-entropy data -- the practical MFMA ceiling next to
     which roofline.frac should be read.  ~0.5 s of GPU time, outside the timed region."""
+    import torch
     n, iters, out = 8192, 20, {}
     a = torch.empty((n, n), dtype=torch.float16, device=dev)
     b = torch.empty((n, n), dtype=torch.float16, device=dev)
@@ -135,25 +151,180 @@ def board_gemm_ceiling(dev):
     return out
 
 
+def other_config(name, dev, w, h, T, tta, img_seed, model, wseed, steps=3):
+    """A further single-GPU BASELINE config, device-resident like `value`: C3 (3840x2160, tile 400) / C5 (1080p, -x TTA)."""
+    import torch
+    import realsr_ncnn_vulkan_amd as R
+    from realsr_ncnn_vulkan_amd import synth
+    d = synth.make_model_dir(os.environ.get("RSR_MODELS", "/tmp/rsr_models"), model, wseed)
+    sr = R.RealSR(dev.index or 0, tta_mode=tta)
+    try:
+        sr.load(os.path.join(d, "x4.param"), os.path.join(d, "x4.bin"))
+        sr.tilesize, sr.prepadding, sr.scale = T, PREPAD, SCALE
+        img = synth.make_image(img_seed, w, h)
+        d_in = torch.from_numpy(img).to(dev)
+        d_out = torch.empty((h * SCALE, w * SCALE, 3), dtype=torch.uint8, device=dev)
+        sr.process_device(d_in.data_ptr(), w, h, 3, d_out.data_ptr())  # warm-up: plan, workspace
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            sr.process_device(d_in.data_ptr(), w, h, 3, d_out.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+        fl = padded_px(w, h, T, PREPAD) * FLOP_PER_PADDED_LR_PX * (8 if tta else 1)
+        return {"config": "%s, %dx%d, tile %d%s, 1 GPU, device-resident" % (model, w, h, T, ", TTA x8 (-x)" if tta else ""),
+                "ms_per_frame": round(dt * 1e3, 2), "value": round(16.0 * w * h / 1e6 / dt, 2), "unit": "Mpix/s", "steps": steps,
+                "frame_tflop": round(fl / 1e12, 1), "frac_of_peak": round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
+                "checksum": int(d_out[::97, ::89].to(torch.int64).sum().item())}
+    finally:
+        sr.close()
+
+
+# ---- the product's own multi-GPU path (config C4): one process, rsr_create_group, shared frame queue ----------------------
+def group_mode(args):
+    import numpy as np
+    import torch
+    import realsr_ncnn_vulkan_amd as R
+    from realsr_ncnn_vulkan_amd import synth
+    n = args.gpus
+    same = os.environ.get("RSR_BENCH_SAME_GPU") == "1"  # 1-GPU test hook: every "GPU" of the group is a context on device 0
+    have = torch.cuda.device_count()
+    if not same and have < n:
+        raise SystemExit("bench.py --mode group --gpus %d: only %d device(s) visible" % (n, have))
+    d = synth.make_model_dir(os.environ.get("RSR_MODELS", "/tmp/rsr_models"), "models-DF2K", 42)
+    pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+    t0 = time.perf_counter()
+    if same:
+        srs, transport = [], "host (RSR_BENCH_SAME_GPU: %d contexts on device 0)" % n
+        for _ in range(n):
+            s = R.RealSR(0)
+            s.load(pp, bp)
+            s.set_option("max_workspace_mb", 24 * 1024)
+            srs.append(s)
+    else:
+        srs, transport = R.create_group(list(range(n)), pp, bp)
+    load_s = time.perf_counter() - t0
+    for s in srs:
+        s.tilesize, s.prepadding, s.scale = TILE, PREPAD, SCALE
+        s._push_params()
+    frames = args.frames
+    jobs = args.jobs_proc
+    src = [synth.make_image(1235 + i, W_IN, H_IN) for i in range(min(frames, 4))]
+    pin_in = []
+    for im in src:
+        p = R.PinnedArray(im.shape)
+        p.array[:] = im
+        pin_in.append(p)
+    outs = [[R.PinnedArray((H_IN * SCALE, W_IN * SCALE, 3)) for _ in range(jobs)] for _ in srs]
+    for gi, s in enumerate(srs):  # warm-up: plans, workspaces, lanes
+        s.process(pin_in[0].array, out=outs[gi][0].array, push_params=False)
+    lock = threading.Lock()
+    nxt = [0]
+    done = [[0] * jobs for _ in srs]
+    sums = {}
+
+    def proc(gi, ji):  # main.cpp:311-331 -- every proc thread of every GPU pops the one shared queue
+        while True:
+            with lock:
+                i = nxt[0]
+                if i >= frames:
+                    return
+                nxt[0] = i + 1
+            srs[gi].process(pin_in[i % len(pin_in)].array, out=outs[gi][ji].array, push_params=False)
+            done[gi][ji] += 1
+            if i < len(pin_in):
+                sums[i] = int(outs[gi][ji].array[::97, ::89].astype(np.int64).sum())
+
+    ths = [threading.Thread(target=proc, args=(gi, ji)) for gi in range(len(srs)) for ji in range(jobs)]
+    t1 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t1
+    # one large image over all contexts, tiles dealt by rsr_process_group
+    big_out = R.PinnedArray((H_IN * SCALE, W_IN * SCALE, 3))
+    R.process_group(srs, pin_in[0].array, out=big_out.array)
+    t2 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        R.process_group(srs, pin_in[0].array, out=big_out.array)
+    dt_one = (time.perf_counter() - t2) / reps
+    one_ok = int(big_out.array[::97, ::89].astype(np.int64).sum()) == sums.get(0)
+    out_mpix = W_IN * SCALE * H_IN * SCALE / 1e6
+    res = {"metric": "output Mpix/s (4x upscale) DF2K tile=200", "mode": "group", "value": round(out_mpix * frames / dt, 3), "unit": "Mpix/s",
+           "n_gpus": n, "frames": frames, "seconds": round(dt, 3), "higher_is_better": True, "scaling": "strong", "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "C4: %d x (1920x1080 -> 7680x4320) frames, models-DF2K, tile 200, host memory -> host memory (pinned), "
+                                  "%d GPUs x jobs_proc %d threads on one shared queue (main.cpp:811-828)" % (frames, n, jobs),
+                      "parallelism": "one process, rsr_create_group: weights by %s; frames from a shared queue, no data-path collective" % transport,
+                      "group_transport": transport, "load_seconds": round(load_s, 3),
+                      "frames_per_gpu": [sum(x) for x in done]},
+           "single_image_over_group": {"what": "ONE C2 frame, its 60 tiles dealt over the %d contexts by rsr_process_group (host -> host)" % n,
+                                       "ms": round(dt_one * 1e3, 2), "value": round(out_mpix / dt_one, 2), "unit": "Mpix/s",
+                                       "bytes_equal_single_context": bool(one_ok)}}
+    print(json.dumps(res), flush=True)
+    for p in pin_in + [big_out] + [o for row in outs for o in row]:
+        p.free()
+    for s in srs:
+        s.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=("ranks", "group"), default="ranks")
+    ap.add_argument("--frames", type=int, default=64, help="group mode: frames in the queue (C4: 64)")
+    ap.add_argument("--jobs-proc", type=int, default=2, help="group mode: proc threads per GPU (the reference's default, main.cpp:708-711)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-host", action="store_true", help="skip the host->host leg")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 legs")
+    ap.add_argument("--no-group", action="store_true", help="N > 1: skip the product-path (rsr_create_group) leg behind the rank run")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    if args.mode == "group":
+        return group_mode(args)
+
+    # ---- N ranks requested but no torch.distributed environment: launch them ourselves (one process per GPU) ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            sys.stdout.write(r.stdout)
+            raise SystemExit("bench.py: the %d-rank run failed (rc %d)" % (args.gpus, r.returncode))
+        j = json.loads(lines[-1])
+        if j.get("n_gpus") != args.gpus:
+            raise SystemExit("bench.py: asked for %d GPUs, the run reports n_gpus=%r" % (args.gpus, j.get("n_gpus")))
+        print(lines[-1], flush=True)
+        return
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import realsr_ncnn_vulkan_amd as R
+    from realsr_ncnn_vulkan_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without torch.distributed.run: "
+                         "this script then starts the ranks itself)" % (args.gpus, world, args.gpus))
     # Test hook for a 1-GPU box: RSR_BENCH_SAME_GPU=1 puts every rank on cuda:0 and RSR_BENCH_BACKEND=gloo replaces RCCL
     # (which refuses two ranks on one device), so the multi-rank control flow can be exercised without 2 GPUs.
     same_gpu = os.environ.get("RSR_BENCH_SAME_GPU") == "1"
     if same_gpu:
         local = 0
-    backend = os.environ.get("RSR_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("RSR_BENCH_BACKEND", "gloo" if same_gpu else "nccl")
+    if not same_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d device(s) visible" % (world, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -183,7 +354,7 @@ def main():
             t.copy_(h)
 
     if rank == 0:
-        blob = torch.from_numpy(R.model_pack(pp, bp, with_w32=False)).to(dev)
+        blob = torch.from_numpy(R.model_pack(pp, bp)).to(dev)
         n = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
     else:
         n = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -218,6 +389,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    wall0 = time.time()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
@@ -225,18 +397,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if rank == 0 and os.environ.get("RSR_BENCH_MARKS"):  # tools/power_sampler.py: power / clock over exactly the timed region
+        with open(os.environ["RSR_BENCH_MARKS"], "w") as f:
+            f.write("%.6f %.6f\n" % (wall0, time.time()))
     prof = sr.get_profile(reset=True) if not args.no_profile else None
     conv_ms = sr.get_conv_times(reset=True) if not args.no_profile else None
     sr.set_profiling(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        if backend == "nccl":
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        else:
-            h = tmax.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.MAX)
-            tmax = h
-    dt = float(tmax.item())
+
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dt = max_over_ranks(dt)
     checksum = int(d_out[::97, ::89].to(torch.int64).sum().item())
 
     # ---- host memory -> host memory: rsr_process incl. H2D / D2H, same frame, same step count ----
@@ -253,20 +428,11 @@ def main():
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 sr.process(src, out=dst, push_params=False)
-            th = time.perf_counter() - t1
-            tt = torch.tensor([th], dtype=torch.float64)
-            if world > 1:
-                if backend == "nccl":
-                    tt = tt.to(dev)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                else:
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            host[name] = float(tt.item())
+            host[name] = max_over_ranks(time.perf_counter() - t1)
         host["identical_to_device_path"] = bool((torch.from_numpy(pin_out.array[::97, ::89].copy()).to(torch.int64).sum().item()) == checksum)
         # two caller threads on the one context (the reference's jobs_proc = 2, main.cpp:811-828): upload of frame k+1 and
         # download of frame k-1 ride under the kernels of frame k
         if world == 1:
-            import threading
             pin_out2 = R.PinnedArray((H_IN * SCALE, W_IN * SCALE, 3))
 
             def worker(dst):
@@ -284,6 +450,7 @@ def main():
         pin_in.free()
         pin_out.free()
 
+    res = None
     if rank == 0:
         out_mpix = W_IN * SCALE * H_IN * SCALE / 1e6
         ppx = padded_px(W_IN, H_IN, TILE, PREPAD)
@@ -300,13 +467,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "value_definition": "images resident in HBM (rsr_process_device); SURVEY 8(d)'s host->host rate is host_to_host below",
+            "value_definition": "images resident in HBM when the timed region starts (rsr_process_device; the driver contract: a PCIe-inclusive "
+                                "rate is never `value`); SURVEY 8(d)'s host->host rate is host_to_host below",
             "config": {
                 "workload": "C2: models-DF2K, 1920x1080 RGB -> 7680x4320, scale=4, tile=200, prepadding=10, "
                             "60 tiles/frame (2,544,000 padded LR px, 91.21 TFLOP algorithmic), 1 frame per GPU per step",
                 "weights": "synthetic seeded fp16-tagged x4.bin (real blobs absent from the reference checkout)",
                 "io": "uint8 HWC in HBM -> uint8 HWC in HBM (rsr_process_device)",
-                "parallelism": ("frames sharded 1/GPU, weights by one RCCL broadcast of %.1f MB" % (blob_bytes / 1e6)) if world > 1 else "single GPU",
+                "parallelism": ("%d ranks (torch.distributed %s, one process per GPU), frames sharded 1/GPU/step, weights by one broadcast of %.1f MB, "
+                                "no data-path collective" % (world, "nccl = RCCL" if backend == "nccl" else backend, blob_bytes / 1e6)) if world > 1 else "single GPU",
                 "frame_tflop": round(ppx * FLOP_PER_PADDED_LR_PX / 1e12, 2),
                 "whole_path_tflops": round(ppx * FLOP_PER_PADDED_LR_PX * world * args.steps / dt / 1e12, 1),
                 "whole_path_frac_of_peak": round(ppx * FLOP_PER_PADDED_LR_PX * world * args.steps / dt / 1e12 / PEAK_F16_TFLOPS / world, 4),
@@ -341,6 +510,7 @@ def main():
             c5_idx = [5 + 5 * j for j in range(69)]
             c5_ms = float(sum(conv_ms[i] for i in c5_idx))
             c5_flops = 2.0 * 9 * 192 * 64 * 69 * ppx * args.steps
+            tail_ms = float(sum(conv_ms[i] for i in (347, 348, 349, 350)))
             traffic, traffic_src = pmc_traffic()
             res["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
@@ -352,11 +522,14 @@ def main():
                 "launches": ring_launches,
                 "avg_launch_us": round(ring_ms * 1e3 / max(ring_launches, 1), 2),
                 "algorithmic_flop_per_launch_avg": round(ring_flops / max(ring_launches, 1)),
+                "flop_accounting": "algorithmic = SURVEY 8(d): every padded-tile pixel of every layer; the kernel executes ~2.6 % more (16x32 "
+                                   "block quantisation in x) and the 2x / 4x convs ~14 % less (blocks that only feed cropped halo pixels are not computed)",
                 "second_kernel": {"kernel": "rsr::conv3x3_flow<2, 1, false, 2, false> (69 x conv5 192 -> 64)",
                                   "achieved": round(c5_flops / (c5_ms * 1e-3) / 1e12, 1), "frac": round(c5_flops / (c5_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                                   "avg_launch_us": round(c5_ms * 1e3 / (69 * args.steps * batches), 2)},
                 "all_convs": {"achieved": round(ach_all, 1), "frac": round(ach_all / PEAK_F16_TFLOPS, 4), "launches": prof["conv_launches"],
                               "conv_ms_per_step": round(prof["conv_ms"] / args.steps, 3)},
+                "tail_ms_per_step": round(tail_ms / args.steps, 3),
                 "pre_ms_per_step": round(prof["pre_ms"] / args.steps, 4),
                 "post_ms_per_step": round(prof["post_ms"] / args.steps, 4),
                 "post_GBps": round(prof["post_bytes"] / max(prof["post_ms"], 1e-9) / 1e6, 1),
@@ -371,15 +544,39 @@ def main():
                     "achieved_over_randn_gemm": round(ach / g["randn"], 4), "all_convs_over_randn_gemm": round(ach_all / g["randn"], 4)}
             except Exception as e:  # noqa: BLE001 -- context only, never fail the bench on it
                 res["roofline"]["vendor_gemm_same_board"] = {"what": "failed: %r" % (e,)}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                res["cpu_baseline"] = cpu_baseline(pp, bp)
-            except Exception as e:  # the oracle is optional here; never fail the GPU number on it
-                res["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(res), flush=True)
     sr.close()
+    del d_in, d_out, blob
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not same_gpu and not args.no_other_configs:
+        # the other single-GPU BASELINE configs, 3 steps each, same definition as `value`
+        res["other_configs"] = {}
+        for name, cfg in (("C3", (3840, 2160, 400, False, 1237, "models-DF2K", 42)), ("C5", (1920, 1080, 200, True, 1239, "models-DF2K_JPEG", 43))):
+            try:
+                res["other_configs"][name] = other_config(name, dev, *cfg)
+            except Exception as e:  # noqa: BLE001 -- never lose the C2 line over a side leg
+                res["other_configs"][name] = {"value": None, "error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(pp, bp)
+        except Exception as e:  # the oracle is optional here; never fail the GPU number on it
+            res["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and world > 1 and not args.no_group:
+        # The product's own multi-GPU path (rsr_create_group: ncclCommInitAll + one ncclBroadcast inside ONE process, proc threads
+        # on a shared queue = config C4) in a child process with a deadline, after every rank has released its GPU: a first-contact
+        # failure there must not cost the rank-mode line.
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", "group", "--gpus", str(world), "--frames", str(max(8 * world, 16))]
+        try:
+            time.sleep(2.0)  # the other ranks are tearing down their contexts
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            res["group_mode"] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"value": None, "error": "rc %d: %s" % (r.returncode, r.stderr[-600:])}
+        except Exception as e:  # noqa: BLE001
+            res["group_mode"] = {"value": None, "error": repr(e)}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -97,11 +97,8 @@ int rsr_set_progress_callback(rsr_ctx* ctx, void (*cb)(int tiles_done, int tiles
  * torch.distributed.broadcast with backend nccl), and every rank loads it with rsr_load_packed. */
 
 /* Host-only: parse + validate + pack into `dst` (capacity `cap` bytes).  *need receives the blob
- * size; call with dst=NULL to query.  No GPU required. */
+ * size (33.5 MB for x4.param); call with dst=NULL to query.  No GPU required. */
 int rsr_model_pack(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need);
-/* with_w32 = 0 leaves out the weight images of the round-1 kernels ("kernel" 1-3): 33.5 MB instead of 67 MB -- the blob
- * the multi-GPU broadcast carries.  rsr_model_pack = with_w32 1. */
-int rsr_model_pack_ex(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need, int with_w32);
 
 /* Load a blob produced by rsr_model_pack.  `blob` may be a host pointer (is_device=0) or a device
  * pointer on this context's GPU (is_device=1). */
@@ -116,13 +113,17 @@ int rsr_load_packed(rsr_ctx* ctx, const void* blob, size_t bytes, int is_device)
 int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, const char* parampath, const char* modelpath);
 const char* rsr_group_transport(void); /* "rccl" | "host ..." for the calling thread's last rsr_create_group */
 
-/* RealSR::process restricted to the tile rows [tile_row_begin, tile_row_end) of the image's tile grid (tiles are independent:
- * realsr.cpp:377-380,458-459).  `in` is the whole image, `out` the whole (4w x 4h x c) output; only the output rows of those
- * tiles are written.  Disjoint row ranges may run concurrently on different contexts into the same `out`. */
+/* RealSR::process restricted to the tiles [tile_begin, tile_end) of the image's tile grid, counted row-major (tile (yi, xi) =
+ * yi * ceil(w / tilesize) + xi; tiles are independent: realsr.cpp:377-380,458-459,490).  `in` is the whole image, `out` the
+ * whole (4w x 4h x c) output; only the output rectangles of those tiles are written.  Disjoint ranges may run concurrently
+ * on different contexts into the same `out`.  rsr_process_rows: the same for whole tile rows [tile_row_begin, tile_row_end). */
+int rsr_process_tiles(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out, int tile_begin, int tile_end);
 int rsr_process_rows(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out, int tile_row_begin, int tile_row_end);
 
-/* One image over n contexts (normally one per GPU): the tile rows are split evenly, every context runs its share on its own
- * thread, the call returns when `out` is complete.  All contexts must carry the same parameters. */
+/* One image over n contexts (normally one per GPU): the TILES are dealt in contiguous row-major ranges of equal padded-pixel
+ * load (within one tile; a 1080p frame at tile 200 = 60 tiles = 7-8 per GPU on 8 GPUs), every context runs its range on its
+ * own thread and fetches the rectangles of its tiles into `out`; the call returns when `out` is complete.  All contexts must
+ * carry the same tilesize / prepadding / scale / tta (checked: RSR_E_ARG otherwise). */
 int rsr_process_group(rsr_ctx* const* ctx, int n, const uint8_t* in, int w, int h, int c, uint8_t* out);
 
 /* Host-only model introspection (no GPU): conv count, weight/bias counts and the .bin encoding
@@ -204,34 +205,29 @@ int rsr_get_conv_times(rsr_ctx* ctx, double* ms, int n, int reset);
 int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
 
 /* Engine knobs (optional).  key/value:
- *   "max_workspace_mb"  tile-batch memory budget (default 65536)
- *   "kernel"            4 [default]: conv3x3_flow -- 16-channel planes, 16-channel half-stage LDS ring, fragments reloaded
- *                       in place across stage and block boundaries, mid-stream barrier, deferred epilogue (conv_flow.hip);
- *                       3: conv3x3_ring (32-output-channel convs) + conv3x3_pipe (64), 2: conv3x3_pipe for everything,
- *                       1: conv3x3_mfma -- the round-1 kernels on 32-channel planes, kept as second implementations
- *   "trunk_fp32"        0 [default]: every feature tensor incl. the residual trunk is stored as fp16, like the
- *                       reference's Vulkan path (use_fp16_storage, realsr.cpp:45); 1: the trunk additionally lives
- *                       in fp32 (halves the pre-quantise error; served by the kernel-3 path, ~-25 % throughput)
- *   "flow_flags"        kernel 4: bit 0 = 64-output-channel convs with 4 MFMA waves x 64 channels instead of 8 x 32,
+ *   "max_workspace_mb"  tile-batch memory budget (default 65536).  The effective budget is additionally bounded by 90 % of the
+ *                       device memory that is actually free when a plan is built, and a batch whose workspace cannot be
+ *                       allocated is halved and re-planned (down to one tile) before RSR_E_NOMEM is reported
+ *   "flow_flags"        bit 0 = 64-output-channel convs with 4 MFMA waves x 64 channels instead of 8 x 32,
  *                       bit 1 = no deferred epilogue for the 32-output-channel convs
+ *   "trim"              1 [default]: blocks / rows of the convs behind the trunk whose output only feeds cropped (halo) pixels of
+ *                       the tile are not computed (dead-output elimination, engine.cpp: tail_margin; output bytes unchanged);
+ *                       0: every padded-tile pixel is computed at every layer
  *   "tail_group"        slots (tiles; x8 under TTA) per launch group of the 2x / 4x convs (default 0 = the whole batch at once).  Small
  *                       groups keep the 4x intermediates in the Infinity Cache between upconv2 -> HRconv -> conv_last; measured
  *                       worth <= 1.5 % of those launches on MI355X and a loss at the 2x level, hence off
  *   "bgr"               1: the caller's images are BGR(A) (the reference's Windows build: WIC decodes to BGR, realsr.cpp:188-206,
  *                       497-515, realsr_preproc.comp:17-21); the network always sees RGB.  Default 0 = RGB(A)
- *   "use_dma"           kernel 1 only: LDS-DMA (1) or register staging (0)
  *   "max_lanes"         rsr_process calls in flight per context (default 4); "chunk_mb": download chunk for pageable
  *                       destinations (default 16); "copy_threads": CPU threads per staging copy of a pageable image
  *                       (default 4; 1 = the calling thread alone)
  *   "num_cu"            persistent grid size (profiling aid)
- *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; kernels 2/3, or a
- *                       -DRSR_FLOW_TRACE build of kernel 4), -1 off
+ *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; -DRSR_FLOW_TRACE builds), -1 off
  *   "alternate_order"   1 [default]: every second conv walks its work items backwards (starts on the tiles the previous conv
  *                       touched last -> Infinity Cache hits); 0: always forwards
  *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
- *                         1 skip LDS-DMA, 2 skip MFMAs (kernels 2/3), 4 skip epilogue stores, 16 generic epilogue everywhere
- *                         (kernels 2/3), 64 direct epilogues (kernels 2/3), 4096 no identity tap (kernels 1-3), 32768 stream weights even
- *                         when resident (kernel 3) */
+ *                         1 skip LDS-DMA, 4 skip epilogue stores, 32 MFMA waves do not skip rows outside the tile / inside the
+ *                         unread frame, 8192 conv_last never writes the uint8 image itself, 16384 no split tail for early download */
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
 
 const char* rsr_last_error(const rsr_ctx* ctx); /* ctx may be NULL: last global (create/pack) error */

@@ -23,9 +23,9 @@ EXPORTS = [
     "rsr_create", "rsr_destroy", "rsr_load", "rsr_set_params", "rsr_process", "rsr_process_device",
     "rsr_model_pack", "rsr_load_packed", "rsr_model_info", "rsr_preproc", "rsr_preproc_tta", "rsr_postproc",
     "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times", "rsr_get_trace",
-    "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_model_pack_ex", "rsr_host_alloc", "rsr_host_free",
+    "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_host_alloc", "rsr_host_free",
     "rsr_set_progress_callback", "rsr_conv3x3_res", "rsr_create_group", "rsr_group_transport", "rsr_process_rows",
-    "rsr_process_group", "rsr_device_memory",
+    "rsr_process_group", "rsr_device_memory", "rsr_process_tiles",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -83,7 +83,6 @@ def lib():
     L.rsr_process.argtypes = [vp, vp, ip, ip, ip, vp]
     L.rsr_process_device.argtypes = [vp, vp, ip, ip, ip, vp, vp]
     L.rsr_model_pack.argtypes = [cp, cp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    L.rsr_model_pack_ex.argtypes = [cp, cp, vp, C.c_size_t, C.POINTER(C.c_size_t), ip]
     L.rsr_device_memory.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.rsr_host_alloc.argtypes = [C.c_size_t]
     L.rsr_host_alloc.restype = vp
@@ -103,6 +102,7 @@ def lib():
     L.rsr_create_group.argtypes = [C.POINTER(vp), C.POINTER(ip), ip, ip, cp, cp]
     L.rsr_group_transport.restype = cp
     L.rsr_process_rows.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip]
+    L.rsr_process_tiles.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip]
     L.rsr_process_group.argtypes = [C.POINTER(vp), ip, vp, ip, ip, ip, vp]
     L.rsr_set_profiling.argtypes = [vp, ip]
     L.rsr_get_profile.argtypes = [vp, C.POINTER(Profile), ip]
@@ -131,16 +131,16 @@ def model_info(param_path, bin_path):
     return dict(n_layers=nl.value, n_convs=nc.value, n_weights=nw.value, n_biases=nb.value, bin_encoding=enc.value)
 
 
-def model_pack(param_path, bin_path, with_w32=True):
-    """Host-only: parse, validate and pack the model into one relocatable blob (np.uint8 array).
-    with_w32=False leaves out the weight images of the round-1 kernels (the broadcast blob)."""
+def model_pack(param_path, bin_path):
+    """Host-only: parse, validate and pack the model into one relocatable blob (np.uint8 array, 33.5 MB): what rsr_load
+    uploads and what the multi-GPU broadcast carries."""
     L = lib()
     need = C.c_size_t()
-    rc = L.rsr_model_pack_ex(str(param_path).encode(), str(bin_path).encode(), None, 0, need, int(with_w32))
+    rc = L.rsr_model_pack(str(param_path).encode(), str(bin_path).encode(), None, 0, need)
     if rc != 0:
         raise RealSRError(rc, L.rsr_last_error(None).decode())
     buf = np.zeros(need.value, dtype=np.uint8)
-    rc = L.rsr_model_pack_ex(str(param_path).encode(), str(bin_path).encode(), _p(buf), buf.size, need, int(with_w32))
+    rc = L.rsr_model_pack(str(param_path).encode(), str(bin_path).encode(), _p(buf), buf.size, need)
     if rc != 0:
         raise RealSRError(rc, L.rsr_last_error(None).decode())
     return buf
@@ -246,6 +246,13 @@ class RealSR:
         h, w, c = img.shape
         self._push_params()
         self._ck(self._L.rsr_process_rows(self._h, _p(img), w, h, c, _p(out), int(row0), int(row1)))
+        return out
+
+    def process_tiles(self, img, out, tile0, tile1):
+        """Tiles [tile0, tile1) of img's row-major tile grid into the full-size `out` (see rsr_process_tiles)."""
+        h, w, c = img.shape
+        self._push_params()
+        self._ck(self._L.rsr_process_tiles(self._h, _p(img), w, h, c, _p(out), int(tile0), int(tile1)))
         return out
 
     def net_forward(self, x):
@@ -361,14 +368,15 @@ def create_group(gpuids, parampath, modelpath, tta_mode=False):
     return srs, L.rsr_group_transport().decode()
 
 
-def process_group(srs, img):
-    """rsr_process_group: ONE image, its tile rows split over the contexts."""
+def process_group(srs, img, out=None):
+    """rsr_process_group: ONE image, its tiles dealt over the contexts in contiguous ranges of equal load."""
     L = lib()
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w, c = img.shape
     for s in srs:
         s._push_params()
-    out = np.empty((h * 4, w * 4, c), dtype=np.uint8)
+    if out is None:
+        out = np.empty((h * 4, w * 4, c), dtype=np.uint8)
     hs = (C.c_void_p * len(srs))(*[s._h for s in srs])
     rc = L.rsr_process_group(hs, len(srs), _p(img), w, h, c, _p(out))
     if rc != 0:

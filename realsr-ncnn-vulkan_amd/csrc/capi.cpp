@@ -8,11 +8,6 @@
 
 using namespace rsr;
 
-struct rsr_ctx // the same definition lives in group.cpp
-{
-    Engine e;
-};
-
 // Errors raised before a context exists (rsr_create, rsr_model_pack) and errors of a context share one per-thread
 // message: rsr_last_error() always reports the calling thread's most recent failure.
 #define g_err_set(msg) ((void)Engine::fail(0, (msg)))
@@ -31,7 +26,7 @@ struct rsr_ctx // the same definition lives in group.cpp
 #pragma GCC visibility push(default)
 extern "C" {
 
-const char* rsr_version(void) { return "realsr-hip 0.2 (gfx950)"; }
+const char* rsr_version(void) { return "realsr-hip 0.3 (gfx950)"; }
 
 // Pinned host memory: images allocated here are copied to / from the GPU without the staging copy (the reference's
 // Vulkan path gets the same effect from its staging allocator, realsr.cpp:161-167).
@@ -136,20 +131,15 @@ int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void
 
 int rsr_model_pack(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need)
 {
-    return rsr_model_pack_ex(parampath, modelpath, dst, cap, need, 1);
-}
-
-int rsr_model_pack_ex(const char* parampath, const char* modelpath, void* dst, size_t cap, size_t* need, int with_w32)
-{
     if (!parampath || !modelpath) return Engine::fail(RSR_E_ARG, "null path");
     Model m;
     std::string err;
     int rc = load_model(parampath, modelpath, m, err);
     if (rc != RSR_OK) return Engine::fail(rc, err);
-    const size_t n = packed_size(m, with_w32 != 0);
+    const size_t n = packed_size(m);
     if (need) *need = n;
     if (!dst) return RSR_OK;
-    rc = pack_model(m, dst, cap, err, with_w32 != 0);
+    rc = pack_model(m, dst, cap, err);
     return rc == RSR_OK ? RSR_OK : Engine::fail(rc, err);
 }
 
@@ -361,9 +351,8 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     {
         if (value < 1) return ctx->e.fail(RSR_E_ARG, "max_workspace_mb must be >= 1");
         ctx->e.max_workspace_mb = value; // plans are keyed by the budget: the next call builds a new one
+        ctx->e.ws_clamp_bytes = -1;
     }
-    else if (k == "trunk_fp32")
-        ctx->e.trunk_fp32 = value != 0;
     else if (k == "tail_group")
     {
         if (value < 0) return ctx->e.fail(RSR_E_ARG, "tail_group must be >= 0");
@@ -371,13 +360,6 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     }
     else if (k == "bgr")
         ctx->e.bgr = value != 0;
-    else if (k == "use_dma")
-        ctx->e.use_dma = value != 0;
-    else if (k == "kernel")
-    {
-        if (value < 1 || value > 4) return ctx->e.fail(RSR_E_ARG, "kernel must be 1, 2, 3 or 4");
-        ctx->e.kernel_version = int(value);
-    }
     else if (k == "flow_flags")
         ctx->e.flow_flags = int(value);
     else if (k == "max_lanes")
@@ -412,6 +394,8 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
                 return ctx->e.fail(RSR_E_DEVICE, "trace buffer clear");
         }
     }
+    else if (k == "trim")
+        ctx->e.trim_tail = value != 0; // plans are keyed by it
     else if (k == "alternate_order")
         ctx->e.alternate_order = value != 0;
     else if (k == "dbg")

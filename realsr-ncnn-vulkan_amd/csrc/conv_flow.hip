@@ -601,6 +601,40 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         return w;
     };
 
+    // A block whose four rows of THIS wave lie wholly below the tile (tile heights are multiples of 4 at every level, blocks of
+    // 16: a 220-row tile ends in the block's third wave, a 100-row tile in its first) -- or wholly inside the frame of output
+    // pixels nothing downstream reads (ConvArgs::margin) -- does no matrix work here: the wave only
+    // keeps the workgroup's barrier cadence -- one per half-stage -- fetches the descriptor the live path would fetch, and
+    // reloads the operands of the next block's first step.  16 x 32 block quantisation otherwise costs 5.4 % of the MFMA
+    // work of a 1080p frame at tile 200 (PMC, round 2), 2.8 points of it in such rows; under the board's power cap skipped
+    // MFMAs + fragment reads are what buys clock.
+    auto wave_is_dead = [&](const WorkItem& w) {
+        const int y = w.y0 + wrow * 4;
+        return (y >= w.H - a.margin || y + 4 <= a.margin) && !(a.dbg & 32);
+    };
+    auto skip_block = [&]() {
+        {
+            const WorkItem* ip_ = a.items + (first + min(r + 2, nmine - 1) * nj);
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(item_q) : "s"(ip_));
+        }
+        for (int h_ = 0; h_ < nst; h_++)
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(item_q)::"memory");
+            sP = sP == PR - 1 ? 0 : sP + 1;
+            sW = sW == WR - 1 ? 0 : sW + 1;
+            t++;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const char* xb = xbase(sP, 0);
+        const char* wb = wbase(sW);
+#pragma unroll
+        for (int q = 0; q < 6; q++) { RSR_LDX(q, xb) }
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) { RSR_LDW(Wa, dy, 0, wb) }
+        if (!DEFER) load_bias();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     unsigned long long t_arr = 0, t_rel = 0;
     (void)t_rel;
     if (tracing) t_arr = __builtin_amdgcn_s_memtime();
@@ -623,6 +657,17 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     {
         for (r = 0; r < nmine; r++)
         {
+            // dead blocks are consumed in a loop of their own IN FRONT of a live block (an if / else around the block body
+            // makes the untouched accumulators meet the live path's fresh ones in phis the register coalescer does not
+            // fold: +64 VGPRs, spills in the 168-VGPR kernels)
+            while (wave_is_dead(it))
+            {
+                skip_block();
+                it = nxt;
+                nxt = item_from_q();
+                if (++r >= nmine) break;
+            }
+            if (r >= nmine) break;
             for (int cp = 0; cp < nst; cp += 2)
             {
                 ck = cp;
@@ -709,139 +754,29 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(p) * unsigned(a.out16.plane_stride)), 0, 0);
         };
-// GENERATED-HOOKS-BEGIN (tools/gen_flow_hooks.py)
-#define RSR_HK_S0(c) RSR_HK_S0_##c
-#define RSR_HK_S0_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][0], v1_ = RSR_OLD[0][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][2], v1_ = RSR_OLD[0][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][4], v1_ = RSR_OLD[0][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][6], v1_ = RSR_OLD[0][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S0_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1(c) RSR_HK_S1_##c
-#define RSR_HK_S1_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][8], v1_ = RSR_OLD[0][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][10], v1_ = RSR_OLD[0][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][12], v1_ = RSR_OLD[0][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[0][0][14], v1_ = RSR_OLD[0][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S1_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2(c) RSR_HK_S2_##c
-#define RSR_HK_S2_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_1 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][0], v1_ = RSR_OLD[1][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_5 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][2], v1_ = RSR_OLD[1][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_9 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 0, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S2_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 0, 1); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3(c) RSR_HK_S3_##c
-#define RSR_HK_S3_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][4], v1_ = RSR_OLD[1][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][6], v1_ = RSR_OLD[1][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][8], v1_ = RSR_OLD[1][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][10], v1_ = RSR_OLD[1][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S3_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4(c) RSR_HK_S4_##c
-#define RSR_HK_S4_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][12], v1_ = RSR_OLD[1][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[1][0][14], v1_ = RSR_OLD[1][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_7 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][0], v1_ = RSR_OLD[2][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S4_11 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][2], v1_ = RSR_OLD[2][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5(c) RSR_HK_S5_##c
-#define RSR_HK_S5_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_1 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_3 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 1, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_5 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 1, 1); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][4], v1_ = RSR_OLD[2][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][6], v1_ = RSR_OLD[2][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S5_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6(c) RSR_HK_S6_##c
-#define RSR_HK_S6_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][8], v1_ = RSR_OLD[2][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][10], v1_ = RSR_OLD[2][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][12], v1_ = RSR_OLD[2][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[2][0][14], v1_ = RSR_OLD[2][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S6_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7(c) RSR_HK_S7_##c
-#define RSR_HK_S7_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_1 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][0], v1_ = RSR_OLD[3][0][1]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_5 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][2], v1_ = RSR_OLD[3][0][3]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[0][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_7 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[0][0][0], pk[0][0][1], pk[0][1][0], pk[0][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_9 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 2, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S7_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 2, 1); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8(c) RSR_HK_S8_##c
-#define RSR_HK_S8_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][4], v1_ = RSR_OLD[3][0][5]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][6], v1_ = RSR_OLD[3][0][7]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[1][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[1][0][0], pk[1][0][1], pk[1][1][0], pk[1][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 0 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_7 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][8], v1_ = RSR_OLD[3][0][9]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_9 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][10], v1_ = RSR_OLD[3][0][11]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[2][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S8_11 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[2][0][0], pk[2][0][1], pk[2][1][0], pk[2][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (0 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9(c) RSR_HK_S9_##c
-#define RSR_HK_S9_0 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_1 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][12], v1_ = RSR_OLD[3][0][13]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][0] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_2 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_3 __builtin_amdgcn_sched_barrier(0); { float v0_ = RSR_OLD[3][0][14], v1_ = RSR_OLD[3][0][15]; v0_ = __builtin_amdgcn_fmed3f(v0_, v0_ * slope, pinf); v1_ = __builtin_amdgcn_fmed3f(v1_, v1_ * slope, pinf); pk[3][1] = half2v{(_Float16)v0_, (_Float16)v1_}; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_4 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_5 __builtin_amdgcn_sched_barrier(0); { half4 o_ = {pk[3][0][0], pk[3][0][1], pk[3][1][0], pk[3][1][1]}; *reinterpret_cast<half4_scr*>(scr + scr_w + 1024 + (16 ^ scr_wx)) = o_; } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_6 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_7 __builtin_amdgcn_sched_barrier(0); { row_from_lds(tq, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_8 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_9 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[0], od, 3, 0); } __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_10 __builtin_amdgcn_sched_barrier(0);
-#define RSR_HK_S9_11 __builtin_amdgcn_sched_barrier(0); { row_store1(tq[1], od, 3, 1); } __builtin_amdgcn_sched_barrier(0);
-// GENERATED-HOOKS-END
+#include "conv_flow_hooks.inc" // RSR_HK_S<step>_<cell>: generated at build time by tools/gen_flow_hooks.py (Makefile)
+    // A dead block first stores the pending set (the one a live block would drain underneath its MFMAs) -- once: `od` is dead
+    // afterwards -- and "defines" its own set with an empty asm: without that the untouched accumulators meet the live path's
+    // fresh ones in phis the register coalescer does not fold (+64 VGPRs = spills).
 #define RSR_BLOCK(ACC)                                                                                               \
+    if (wave_is_dead(it))                                                                                            \
+    {                                                                                                                \
+        if (od.live)                                                                                                 \
+        {                                                                                                            \
+            _Pragma("unroll") for (int rr = 0; rr < 4; rr++)                                                         \
+            {                                                                                                        \
+                row_to_lds(RSR_OLD[rr][0], 0);                                                                       \
+                row_from_lds(tq, 0);                                                                                 \
+                row_store(tq, od, rr, 0);                                                                            \
+            }                                                                                                        \
+        }                                                                                                            \
+        skip_block();                                                                                                \
+        _Pragma("unroll") for (int rr = 0; rr < 4; rr++) asm volatile("" : "=v"(ACC[rr][0]));                        \
+        od = make_out(it, false);                                                                                    \
+        it = nxt;                                                                                                    \
+        nxt = item_from_q();                                                                                         \
+    }                                                                                                                \
+    else                                                                                                             \
     {                                                                                                                \
         ck = 0;                                                                                                      \
         RSR_HALF(ACC, Wa, Wb, true, RSR_HK_S0, 0, RSR_HK_S1, 0, RSR_HK_S2, 0)                                        \
@@ -877,7 +812,6 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // drain the last block
         if (nmine & 1)
         {
 #pragma unroll
@@ -899,138 +833,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             }
         }
 #undef RSR_BLOCK
-// GENERATED-UNDEFS-BEGIN (tools/gen_flow_hooks.py)
-#undef RSR_HK_S0
-#undef RSR_HK_S0_0
-#undef RSR_HK_S0_1
-#undef RSR_HK_S0_2
-#undef RSR_HK_S0_3
-#undef RSR_HK_S0_4
-#undef RSR_HK_S0_5
-#undef RSR_HK_S0_6
-#undef RSR_HK_S0_7
-#undef RSR_HK_S0_8
-#undef RSR_HK_S0_9
-#undef RSR_HK_S0_10
-#undef RSR_HK_S0_11
-#undef RSR_HK_S1
-#undef RSR_HK_S1_0
-#undef RSR_HK_S1_1
-#undef RSR_HK_S1_2
-#undef RSR_HK_S1_3
-#undef RSR_HK_S1_4
-#undef RSR_HK_S1_5
-#undef RSR_HK_S1_6
-#undef RSR_HK_S1_7
-#undef RSR_HK_S1_8
-#undef RSR_HK_S1_9
-#undef RSR_HK_S1_10
-#undef RSR_HK_S1_11
-#undef RSR_HK_S2
-#undef RSR_HK_S2_0
-#undef RSR_HK_S2_1
-#undef RSR_HK_S2_2
-#undef RSR_HK_S2_3
-#undef RSR_HK_S2_4
-#undef RSR_HK_S2_5
-#undef RSR_HK_S2_6
-#undef RSR_HK_S2_7
-#undef RSR_HK_S2_8
-#undef RSR_HK_S2_9
-#undef RSR_HK_S2_10
-#undef RSR_HK_S2_11
-#undef RSR_HK_S3
-#undef RSR_HK_S3_0
-#undef RSR_HK_S3_1
-#undef RSR_HK_S3_2
-#undef RSR_HK_S3_3
-#undef RSR_HK_S3_4
-#undef RSR_HK_S3_5
-#undef RSR_HK_S3_6
-#undef RSR_HK_S3_7
-#undef RSR_HK_S3_8
-#undef RSR_HK_S3_9
-#undef RSR_HK_S3_10
-#undef RSR_HK_S3_11
-#undef RSR_HK_S4
-#undef RSR_HK_S4_0
-#undef RSR_HK_S4_1
-#undef RSR_HK_S4_2
-#undef RSR_HK_S4_3
-#undef RSR_HK_S4_4
-#undef RSR_HK_S4_5
-#undef RSR_HK_S4_6
-#undef RSR_HK_S4_7
-#undef RSR_HK_S4_8
-#undef RSR_HK_S4_9
-#undef RSR_HK_S4_10
-#undef RSR_HK_S4_11
-#undef RSR_HK_S5
-#undef RSR_HK_S5_0
-#undef RSR_HK_S5_1
-#undef RSR_HK_S5_2
-#undef RSR_HK_S5_3
-#undef RSR_HK_S5_4
-#undef RSR_HK_S5_5
-#undef RSR_HK_S5_6
-#undef RSR_HK_S5_7
-#undef RSR_HK_S5_8
-#undef RSR_HK_S5_9
-#undef RSR_HK_S5_10
-#undef RSR_HK_S5_11
-#undef RSR_HK_S6
-#undef RSR_HK_S6_0
-#undef RSR_HK_S6_1
-#undef RSR_HK_S6_2
-#undef RSR_HK_S6_3
-#undef RSR_HK_S6_4
-#undef RSR_HK_S6_5
-#undef RSR_HK_S6_6
-#undef RSR_HK_S6_7
-#undef RSR_HK_S6_8
-#undef RSR_HK_S6_9
-#undef RSR_HK_S6_10
-#undef RSR_HK_S6_11
-#undef RSR_HK_S7
-#undef RSR_HK_S7_0
-#undef RSR_HK_S7_1
-#undef RSR_HK_S7_2
-#undef RSR_HK_S7_3
-#undef RSR_HK_S7_4
-#undef RSR_HK_S7_5
-#undef RSR_HK_S7_6
-#undef RSR_HK_S7_7
-#undef RSR_HK_S7_8
-#undef RSR_HK_S7_9
-#undef RSR_HK_S7_10
-#undef RSR_HK_S7_11
-#undef RSR_HK_S8
-#undef RSR_HK_S8_0
-#undef RSR_HK_S8_1
-#undef RSR_HK_S8_2
-#undef RSR_HK_S8_3
-#undef RSR_HK_S8_4
-#undef RSR_HK_S8_5
-#undef RSR_HK_S8_6
-#undef RSR_HK_S8_7
-#undef RSR_HK_S8_8
-#undef RSR_HK_S8_9
-#undef RSR_HK_S8_10
-#undef RSR_HK_S8_11
-#undef RSR_HK_S9
-#undef RSR_HK_S9_0
-#undef RSR_HK_S9_1
-#undef RSR_HK_S9_2
-#undef RSR_HK_S9_3
-#undef RSR_HK_S9_4
-#undef RSR_HK_S9_5
-#undef RSR_HK_S9_6
-#undef RSR_HK_S9_7
-#undef RSR_HK_S9_8
-#undef RSR_HK_S9_9
-#undef RSR_HK_S9_10
-#undef RSR_HK_S9_11
-// GENERATED-UNDEFS-END
+#include "conv_flow_hooks_undef.inc"
     }
 #undef RSR_HALF_PLAIN
 #undef RSR_HALF
@@ -1094,13 +897,13 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
     if (((a.n0 + a.n1) & 1) || !a.wpk16) return false;
     const bool ups = a.lvl_out != a.lvl_in;
     int epi = 0;
-    if (a.out16.base && !a.out32a.base && !a.out32b.base && !a.out_planar3)
+    if (a.out16.base && !a.out_planar3 && !a.out_u8)
     {
         if (a.res1_kind == 0 && a.res2_kind == 0) epi = 1;
         else if (a.res1_kind == 1 && (a.res2_kind == 0 || a.res2_kind == 1)) epi = 2;
         else return false;
     }
-    else if ((!a.out_planar3 && !a.out_u8) || a.out16.base || a.out32a.base || a.out32b.base || a.res1_kind || a.res2_kind) return false;
+    else if ((!a.out_planar3 && !a.out_u8) || a.out16.base || a.res1_kind || a.res2_kind) return false;
     const bool ntw2 = (flags & 1) != 0, defer = !(flags & 2);
     if (nt == 1)
     {

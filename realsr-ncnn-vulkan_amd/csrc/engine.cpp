@@ -89,7 +89,7 @@ Engine::~Engine()
         if (l->copy) (void)hipStreamDestroy(l->copy);
     }
     free_plans();
-    DevBuf* all[] = {&blob, &zeros, &b_in, &b_fea, &b_rdb[0], &b_rdb[1], &b_rdb[2], &b_t32, &b_r32, &b_up1, &b_up2, &b_hr, &b_out3, &trace_buf};
+    DevBuf* all[] = {&blob, &zeros, &b_in, &b_fea, &b_rdb[0], &b_rdb[1], &b_rdb[2], &b_up1, &b_up2, &b_hr, &b_out3, &trace_buf};
     for (DevBuf* b : all)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -190,7 +190,6 @@ int Engine::load_blob_host(const void* data, size_t bytes)
     const PackedHeader* H = static_cast<const PackedHeader*>(data);
     const PackedConv* T = reinterpret_cast<const PackedConv*>(static_cast<const unsigned char*>(data) + sizeof(PackedHeader));
     convs.assign(T, T + H->nconv);
-    has_w32 = (H->flags & 1u) != 0;
     loaded = true;
     return RSR_OK;
 }
@@ -218,7 +217,6 @@ int Engine::load_blob_device(const void* data, size_t bytes)
     const PackedHeader* H = reinterpret_cast<const PackedHeader*>(head.data());
     const PackedConv* T = reinterpret_cast<const PackedConv*>(head.data() + sizeof(PackedHeader));
     convs.assign(T, T + H->nconv);
-    has_w32 = (H->flags & 1u) != 0;
     loaded = true;
     return RSR_OK;
 }
@@ -246,14 +244,42 @@ void Engine::free_plans()
     plans.clear();
 }
 
-// crop4 = prepadding * scale, or < 0 when the slots are not the tiles themselves (TTA: 8 slots per tile, net_forward)
-static void make_items(Plan::Batch& b, int crop4 = -1)
+// Dead-output elimination behind the trunk.  The caller keeps only the un-padded rectangle of a tile's output: pixels closer
+// than crop4 = prepadding * scale to the tile border are cropped (realsr_postproc.comp:62-69, realsr.cpp:460-461).  Walking
+// back from there, every 3x3 conv needs one more ring of its input: conv_last's output is read from margin crop4 inwards,
+// HRconv's from crop4 - 1, upconv2's from crop4 - 2; upconv2 reads the nearest-x2 of upconv1's output (2x level) from
+// (crop4 - 3) >> 1 = crop4 / 2 - 2, and so on through the last LR convs.  Output pixels outside those regions influence
+// nothing that is kept, so their blocks are left out of the work-item tables (block granularity, here) and their 4-row groups
+// are skipped by the MFMA waves (ConvArgs::margin).  The bytes of the kept rectangle are unchanged -- this is what a
+// compiler calls dead-code elimination; the algorithmic FLOP count still counts the halo densely.
+static int tail_margin(int crop4, int which) // which: 0 conv_last, 1 HRconv, 2 upconv2 (4x level), 3 upconv1 (2x level), 4.. LR convs backwards
 {
+    if (crop4 <= 0) return 0;
+    int m;
+    if (which <= 2) m = crop4 - which;
+    else
+    {
+        m = crop4 / 2 - 2; // upconv1: (crop4 - 3) >> 1 below, the same above for the even crops prepadding * 4 gives
+        if (which >= 4)
+        {
+            m = (m - 1) >> 1;  // trunk_conv: read by upconv1 through the nearest-x2 gather
+            m -= (which - 4);  // RDB 69 conv5, conv4, ... each one ring further out
+        }
+    }
+    return m > 0 ? m : 0;
+}
+
+// place4 = prepadding * scale when the slots ARE the tiles (non-TTA: conv_last may write the image itself), < 0 otherwise
+// (TTA: 8 slots per tile, net_forward); trim4 = prepadding * scale when only the cropped rectangle is kept, 0 = keep all
+static void make_items(Plan::Batch& b, int place4 = -1, int trim4 = 0)
+{
+    const int margin[3] = {0, tail_margin(trim4, 3), tail_margin(trim4, 2)}; // per level: the smallest margin of its convs
     for (int lvl = 0; lvl < 3; lvl++)
     {
         b.items[lvl].clear();
         b.item_start[lvl].assign(size_t(b.nslots) + 1, 0);
         b.px[lvl] = 0;
+        const int m = margin[lvl];
         for (int s = 0; s < b.nslots; s++)
         {
             b.item_start[lvl][size_t(s)] = int(b.items[lvl].size());
@@ -261,15 +287,19 @@ static void make_items(Plan::Batch& b, int crop4 = -1)
             b.px[lvl] += double(H) * W;
             // 4x-level items carry the tile's placement in the output image: conv_last can write the uint8 image itself
             int p0 = 0, p1 = 0, p2 = 0;
-            if (lvl == 2 && crop4 >= 0 && size_t(s) < b.tiles.size())
+            if (lvl == 2 && place4 >= 0 && size_t(s) < b.tiles.size())
             {
                 const BaseTile& t = b.tiles[size_t(s)];
-                p0 = t.out_x - crop4;
-                p1 = t.out_y - crop4;
+                p0 = t.out_x - place4;
+                p1 = t.out_y - place4;
                 p2 = t.out_w | (t.out_h << 16);
             }
             for (int y0 = 0; y0 < H; y0 += kBlkH)
-                for (int x0 = 0; x0 < W; x0 += kBlkW) b.items[lvl].push_back(WorkItem{s, y0, x0, H, W, p0, p1, p2});
+                for (int x0 = 0; x0 < W; x0 += kBlkW)
+                {
+                    if (y0 + kBlkH <= m || y0 >= H - m || x0 + kBlkW <= m || x0 >= W - m) continue; // nothing kept depends on it
+                    b.items[lvl].push_back(WorkItem{s, y0, x0, H, W, p0, p1, p2});
+                }
         }
         b.item_start[lvl][size_t(b.nslots)] = int(b.items[lvl].size());
     }
@@ -305,16 +335,15 @@ static hipError_t upload_batch(Plan::Batch& b, char*& d)
     return err;
 }
 
-// per-slot workspace bytes per LR pixel: IN 64, FEA 128, 3 x RDB 384, T32 256, R32 256, UP1 4*128,
-// UP2 16*128, HR 16*128, OUT3 16*6   (the same for 16- and 32-channel planes)
-static constexpr long long kBytesPerPx = 64 + 128 + 3 * 384 + 256 + 256 + 512 + 2048 + 2048 + 96;
+// per-slot workspace bytes per LR pixel: IN 64, FEA 128, 3 x RDB 384, UP1 4*128, UP2 16*128, HR 16*128, OUT3 16*6
+static constexpr long long kBytesPerPx = 64 + 128 + 3 * 384 + 512 + 2048 + 2048 + 96;
 static constexpr size_t kMaxPlans = 8;
 
-int Engine::get_plan(int w, int h, int c, int row0, int row1, Plan*& out)
+int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
 {
     for (auto it = plans.begin(); it != plans.end(); ++it)
         if (it->w == w && it->h == h && it->c == c && it->T == tilesize && it->P == prepadding && it->tta == tta &&
-            it->row0 == row0 && it->row1 == row1 && it->budget_mb == max_workspace_mb)
+            it->tile0 == tile0 && it->tile1 == tile1 && it->budget_mb == max_workspace_mb && it->trim == trim_tail)
         {
             plans.splice(plans.begin(), plans, it); // most recently used first
             out = &plans.front();
@@ -326,10 +355,10 @@ int Engine::get_plan(int w, int h, int c, int row0, int row1, Plan*& out)
     std::vector<BaseTile> all;
     long long cap = 0;
     int mtw = 0, mth = 0;
-    if (row0 < 0 || row1 > ytiles || row0 >= row1) return fail(RSR_E_ARG, "tile row range outside the image");
-    for (int yi = row0; yi < row1; yi++)
-        for (int xi = 0; xi < xtiles; xi++)
+    if (tile0 < 0 || tile1 > xtiles * ytiles || tile0 >= tile1) return fail(RSR_E_ARG, "tile range outside the image");
+    for (int ti = tile0; ti < tile1; ti++)
         {
+            const int yi = ti / xtiles, xi = ti - yi * xtiles;
             const int twn = std::min((xi + 1) * T, w) - xi * T;
             const int thn = std::min((yi + 1) * T, h) - yi * T;
             BaseTile t;
@@ -358,7 +387,26 @@ int Engine::get_plan(int w, int h, int c, int row0, int row1, Plan*& out)
         return fail(RSR_E_ARG, "tilesize too large: a padded tile may have at most 2,097,151 pixels (e.g. -t 1400)");
     const int per = tta ? 8 : 1;
     const long long per_slot = cap * kBytesPerPx;
-    long long budget_slots = (max_workspace_mb * 1024 * 1024) / std::max<long long>(per_slot, 1);
+    // Memory policy (the reference bounds device memory through the tile size alone, main.cpp:761-774; here ALL tiles of an image
+    // form one batch, so the batch is what must be bounded): the budget is max_workspace_mb, but never more than 90 % of what
+    // the device can actually give this engine right now -- free memory + the workspace it already holds - the image buffers
+    // of its lanes -- and never more than a size that has already failed to allocate (ws_clamp_bytes, enqueue_image's retry).
+    long long budget = max_workspace_mb * 1024 * 1024;
+    {
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) == hipSuccess)
+        {
+            long long held = 0;
+            for (const DevBuf* wb : {&b_in, &b_fea, &b_rdb[0], &b_rdb[1], &b_rdb[2], &b_up1, &b_up2, &b_hr, &b_out3}) held += (long long)wb->bytes;
+            const long long lanes_need = (long long)max_lanes * 17 * w * h * c;
+            const long long avail = ((long long)f + held) / 10 * 9 - lanes_need;
+            budget = std::min(budget, std::max<long long>(avail, per_slot * per));
+        }
+        else
+            (void)hipGetLastError();
+    }
+    if (ws_clamp_bytes >= 0) budget = std::min(budget, std::max<long long>(ws_clamp_bytes, per_slot * per));
+    long long budget_slots = budget / std::max<long long>(per_slot, 1);
     budget_slots = std::max<long long>(per, budget_slots / per * per);
     const long long total_slots = (long long)all.size() * per;
     const int spb = int(std::min<long long>(total_slots, budget_slots));
@@ -366,8 +414,9 @@ int Engine::get_plan(int w, int h, int c, int row0, int row1, Plan*& out)
 
     Plan plan;
     plan.w = w; plan.h = h; plan.c = c; plan.T = T; plan.P = P; plan.tta = tta;
-    plan.row0 = row0; plan.row1 = row1;
+    plan.tile0 = tile0; plan.tile1 = tile1;
     plan.budget_mb = max_workspace_mb;
+    plan.trim = trim_tail;
     plan.cap_px = cap;
     plan.max_tw = mtw;
     plan.max_th = mth;
@@ -387,7 +436,8 @@ int Engine::get_plan(int w, int h, int c, int row0, int row1, Plan*& out)
             for (int k = 0; k < per; k++)
                 b.dims.push_back(k < 4 ? TileDim{t.th, t.tw} : TileDim{t.tw, t.th}); // realsr.cpp:251-258
         }
-        make_items(b, tta ? -1 : P * scale);
+        b.trim4 = trim_tail ? P * scale : 0;
+        make_items(b, tta ? -1 : P * scale, b.trim4);
         table_bytes += batch_table_bytes(b);
         plan.batches.push_back(std::move(b));
     }
@@ -439,36 +489,42 @@ int Engine::ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool l
 
 int Engine::ensure_workspace(int nslots, long long cap, hipStream_t st)
 {
-    const int pc = plane_ch();
+    constexpr int pc = plane_ch();
     const size_t n = size_t(nslots), c = size_t(cap), G = size_t(kGuard), ppx = size_t(pc) * 2;
     const size_t p32 = size_t(32 / pc), p64 = size_t(64 / pc);
-    const bool lc = (cap != ws_cap_px) || (pc != ws_plane_ch); // plane stride (hence guard positions) depends on both
+    const bool lc = cap != ws_cap_px; // the plane stride (hence the guard positions) depends on the slot capacity
     const size_t need[] = {n * p32 * (c * ppx + G), n * p64 * (c * ppx + G), n * 3 * p64 * (c * ppx + G), n * p64 * (c * 4 * ppx + G),
-                           n * p64 * (c * 16 * ppx + G), n * c * 96, trunk_fp32 ? n * c * 256 : 0};
-    DevBuf* const bufs[] = {&b_in, &b_fea, &b_rdb[0], &b_up1, &b_up2, &b_out3, &b_t32};
+                           n * p64 * (c * 16 * ppx + G), n * c * 96};
+    DevBuf* const bufs[] = {&b_in, &b_fea, &b_rdb[0], &b_up1, &b_up2, &b_out3};
     bool any_grow = false;
-    for (int i = 0; i < 7; i++)
+    for (int i = 0; i < 6; i++)
         if (need[i] && !(bufs[i]->bytes >= need[i] && bufs[i]->p)) any_grow = true;
     if (any_grow || lc) HIP_TRY(hipStreamSynchronize(st)); // nothing in flight may use a buffer that is freed / re-laid-out
     int rc;
-    // b_in: with 16-channel planes its second plane (channels 16..31 of the padded 3-channel input) must stay zero
+    // b_in: its second plane (channels 16..31 of the padded 3-channel input) must stay zero
     if ((rc = ensure_planes(b_in, need[0], long(c * ppx + G), lc, true, st)) != RSR_OK) return rc;
     if ((rc = ensure_planes(b_fea, need[1], long(c * ppx + G), lc, false, st)) != RSR_OK) return rc;
     for (int i = 0; i < 3; i++)
         if ((rc = ensure_planes(b_rdb[i], need[2], long(c * ppx + G), lc, false, st)) != RSR_OK) return rc;
-    if (trunk_fp32)
-    {
-        if ((rc = ensure(b_t32, n * c * 256)) != RSR_OK) return rc;
-        if ((rc = ensure(b_r32, n * c * 256)) != RSR_OK) return rc;
-    }
     if ((rc = ensure_planes(b_up1, need[3], long(c * 4 * ppx + G), lc, false, st)) != RSR_OK) return rc;
     if ((rc = ensure_planes(b_up2, need[4], long(c * 16 * ppx + G), lc, false, st)) != RSR_OK) return rc;
     if ((rc = ensure_planes(b_hr, need[4], long(c * 16 * ppx + G), lc, false, st)) != RSR_OK) return rc;
     if ((rc = ensure(b_out3, need[5])) != RSR_OK) return rc;
     HIP_TRY(hipGetLastError());
     ws_cap_px = cap;
-    ws_plane_ch = pc;
     return RSR_OK;
+}
+
+void Engine::free_workspace(hipStream_t st)
+{
+    (void)hipStreamSynchronize(st);
+    for (DevBuf* wb : {&b_in, &b_fea, &b_rdb[0], &b_rdb[1], &b_rdb[2], &b_up1, &b_up2, &b_hr, &b_out3})
+    {
+        if (wb->p) (void)hipFree(wb->p);
+        wb->p = nullptr;
+        wb->bytes = 0;
+    }
+    ws_cap_px = 0;
 }
 
 // ---- profiling ------------------------------------------------------------------------------
@@ -538,19 +594,8 @@ void Engine::collect_profile(hipStream_t st)
 int Engine::launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st)
 {
     const PackedConv& c = convs[size_t(ci)];
-    const int kv = eff_kernel();
-    if (kv >= 4)
-    {
-        if (!launch_conv_flow(a, int(c.nt), num_cu, flow_flags, st))
-            return fail(RSR_E_STATE, "conv3x3_flow has no variant for convolution " + std::to_string(ci));
-    }
-    else
-    {
-        if (!has_w32) return fail(RSR_E_STATE, "this blob carries no 32-channel weight images (kernel 1-3 need rsr_model_pack's full blob)");
-        if (kv == 3 && c.nt == 1 && launch_conv_ring(a, int(c.nt), num_cu, st)) {}
-        else if (kv >= 2) launch_conv_pipe(a, int(c.nt), num_cu, st);
-        else launch_conv(a, int(c.nt), use_dma, st);
-    }
+    if (!launch_conv_flow(a, int(c.nt), num_cu, flow_flags, st))
+        return fail(RSR_E_STATE, "conv3x3_flow has no variant for convolution " + std::to_string(ci));
     const double frac = b.items[a.lvl_out].empty() ? 1.0 : double(a.nitems) / double(b.items[a.lvl_out].size()); // split launches
     mark(1, 2.0 * 9.0 * c.cin * c.cout * b.px[a.lvl_out] * frac, 0, st, ci);
     return RSR_OK;
@@ -561,17 +606,10 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
     const long long cap = ws_cap_px;
     const int pc = plane_ch(), P32 = 32 / pc, P64 = 64 / pc;
     const long long ppx = pc * 2;
-    const long long pb16 = cap * ppx + kGuard, pb32 = cap * 128; // fp16 planes are guarded (see ensure_workspace)
+    const long long pb16 = cap * ppx + kGuard; // planes are guarded (see ensure_workspace)
     auto PS = [](const DevBuf& buf, long long planes_per_slot, long long plane_bytes, int plane_off) {
         PlaneSrc s; // base = pixel 0 of plane `plane_off` of slot 0
         s.base = static_cast<const char*>(buf.p) + (long long)plane_off * plane_bytes + kGuard;
-        s.slot_stride = planes_per_slot * plane_bytes;
-        s.plane_stride = plane_bytes;
-        return s;
-    };
-    auto PS32 = [](const DevBuf& buf, long long planes_per_slot, long long plane_bytes, int plane_off) {
-        PlaneSrc s; // fp32 trunk planes: never a DMA source, no guard
-        s.base = static_cast<const char*>(buf.p) + (long long)plane_off * plane_bytes;
         s.slot_stride = planes_per_slot * plane_bytes;
         s.plane_stride = plane_bytes;
         return s;
@@ -582,7 +620,6 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         ConvArgs a;
         std::memset(&a, 0, sizeof a);
         const PackedConv& c = convs[size_t(ci)];
-        a.wpk = has_w32 ? blobp + c.w_off : nullptr;
         a.wpk16 = blobp + c.w16_off;
         a.bias = reinterpret_cast<const float*>(blobp + c.b_off);
         a.lrelu = (c.act == 2);
@@ -598,6 +635,8 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         a.dbg = dbg;
         a.trace = (trace_conv == ci) ? static_cast<unsigned long long*>(trace_buf.p) : nullptr;
         a.s1 = a.s2 = 1.f;
+        // x4.param order: ... RDB 69 (ci 341..345) | trunk_conv 346 | upconv1 347 | upconv2 348 | HRconv 349 | conv_last 350
+        a.margin = tail_margin(b.trim4, ci >= 347 ? 350 - ci : 4 + (346 - ci));
         return a;
     };
     auto go = [&](ConvArgs& a) {
@@ -605,16 +644,14 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         ci++;
     };
     const PlaneSrc fea = PS(b_fea, P64, pb16, 0);
-    const PlaneSrc t32 = PS32(b_t32, 2, pb32, 0), r32 = PS32(b_r32, 2, pb32, 0);
     auto rdb_x = [&](int i) { return PS(b_rdb[i], 3 * P64, pb16, 0); };
     auto rdb_d = [&](int i, int k) { return PS(b_rdb[i], 3 * P64, pb16, P64 + k * P32); };
 
-    { // conv_first (x4.param:4): IN -> FEA (+ fp32 trunk copies)
+    { // conv_first (x4.param:4): IN -> FEA
         ConvArgs a = base_args(0, 0);
         a.src0 = PS(b_in, P32, pb16, 0);
         a.n0 = P32;
         a.out16 = fea;
-        if (trunk_fp32) { a.out32a = t32; a.out32b = r32; }
         go(a);
     }
     for (int j = 0; j < kNumRDB; j++)
@@ -635,13 +672,11 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         a.src0 = xs; a.n0 = P64;
         a.src1 = rdb_d(bi, 0); a.n1 = 4 * P32;
         a.s1 = 0.2f;
-        if (trunk_fp32) { a.res1 = t32; a.res1_kind = 2; a.out32a = t32; }
-        else { a.res1 = xs; a.res1_kind = 1; a.res1_in_acc = plane_ch() == 16 || !(dbg & 4096); a.res1_coef = 5.f; } // 1/0.2, exact in fp16
+        a.res1 = xs; a.res1_kind = 1; a.res1_in_acc = 1; a.res1_coef = 5.f; // 1/0.2, exact in fp16
         if (bi == 2)
         {
             a.s2 = 0.2f;
-            if (trunk_fp32) { a.res2 = r32; a.res2_kind = 2; a.out32b = r32; }
-            else { a.res2 = (j == 2) ? fea : rdb_x(0); a.res2_kind = 1; }
+            a.res2 = (j == 2) ? fea : rdb_x(0); a.res2_kind = 1;
         }
         a.out16 = rdb_x((j + 1) % 3);
         go(a);
@@ -725,18 +760,34 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
 
 // ---- process ----------------------------------------------------------------------------------
 // enqueue preproc -> network -> postproc for every tile batch of one image on `st` (mu held)
-int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0, int row1, hipEvent_t ev_half,
+int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int tile0, int tile1, hipEvent_t ev_half,
                           size_t* half_rows)
 {
     if (half_rows) *half_rows = 0;
     Plan* planp = nullptr;
-    if (row1 < 0) row1 = (h + tilesize - 1) / tilesize;
-    int rc = get_plan(w, h, c, row0, row1, planp);
+    const int xtiles = (w + tilesize - 1) / tilesize;
+    if (tile1 < 0) tile1 = xtiles * ((h + tilesize - 1) / tilesize);
+    int rc;
+    for (;;)
+    {
+        rc = get_plan(w, h, c, tile0, tile1, planp);
+        if (rc != RSR_OK) return rc;
+        rc = ensure_workspace(planp->slots_per_batch, planp->cap_px, st);
+        if (rc != RSR_E_NOMEM) break;
+        // The batch does not fit (a shared or partly used GPU): halve it and plan again, down to one tile (x8 under TTA).
+        const int per = tta ? 8 : 1;
+        if (planp->slots_per_batch <= per) return rc;
+        const std::string why = last_error();
+        const long long half_slots = std::max<long long>(per, (planp->slots_per_batch / 2) / per * per);
+        ws_clamp_bytes = half_slots * planp->cap_px * kBytesPerPx;
+        free_workspace(st); // partly grown buffers go back first; the stream is drained, so the plan's tables are idle too
+        if (planp->d_tables) (void)hipFree(planp->d_tables);
+        plans.pop_front(); // get_plan put it in front
+        (void)why;
+    }
     if (rc != RSR_OK) return rc;
     const Plan& plan = *planp;
-    rc = ensure_workspace(plan.slots_per_batch, plan.cap_px, st);
-    if (rc != RSR_OK) return rc;
-    const int pc = plane_ch();
+    constexpr int pc = plane_ch();
     mark_begin(st);
     int done = 0, total = 0;
     for (const Plan::Batch& b : plan.batches) total += b.ntiles;
@@ -755,13 +806,13 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         launch_preproc_tiles(pa, plan.max_tw, plan.max_th, st);
         mark(0, 0, b.px[0] / (tta ? 8 : 1) * c + b.px[0] * 64, st);
         // conv_last writes the uint8 image directly when no TTA merge / alpha channel needs the fp16 blob (dbg 8192: off)
-        const bool fused = !tta && c == 3 && eff_kernel() >= 4 && !(dbg & 8192);
+        const bool fused = !tta && c == 3 && !(dbg & 8192);
         // host calls: split the 4x tail at a tile-row boundary so that the first output rows can travel while the rest is computed
         int split_slot = 0;
         if (fused && ev_half && half_rows && plan.batches.size() == 1 && !profiling && !(dbg & 16384))
         {
-            const int xt = (w + tilesize - 1) / tilesize, yt = b.ntiles / xt;
-            if (yt >= 2 && b.ntiles == xt * yt)
+            const int xt = xtiles, yt = b.ntiles / xt;
+            if (yt >= 2 && b.ntiles == xt * yt && plan.tile0 % xt == 0)
             {
                 split_slot = xt * (yt / 2);
                 *half_rows = size_t(b.tiles[size_t(split_slot)].out_y - b.tiles[0].out_y); // output rows finished at ev_half
@@ -904,16 +955,37 @@ static int ensure_pinned(void*& p, size_t& have, size_t need)
 // stream (ordered by events), download on the copy stream again.  Pinned caller memory (rsr_host_alloc, hipHostMalloc,
 // hipHostRegister) is copied directly; pageable memory goes through the lane's pinned staging, the download in chunks so
 // that the CPU copy of chunk i overlaps the PCIe transfer of chunk i+1.
-int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, int row0, int row1)
+// tile0 / tile1: only tiles [tile0, tile1) of the row-major tile grid (tiles are independent: realsr.cpp:377-380,458-459,490).
+// A range of whole tile rows is a contiguous byte range of the output; a general range is up to three rectangles -- the
+// tail of its first tile row, whole rows, the head of its last row -- fetched with 2-D copies.
+int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, int tile0, int tile1)
 {
     if (!in || !out || w < 1 || h < 1 || (c != 3 && c != 4)) return fail(RSR_E_ARG, "bad image arguments");
     const size_t nin = size_t(w) * h * c, nout_full = nin * size_t(scale) * scale;
+    int T = 0;
+    { // state checks BEFORE anything is enqueued on behalf of this call
+        std::lock_guard<std::mutex> lk(mu);
+        if (!loaded) return fail(RSR_E_STATE, "process before load");
+        if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
+        T = tilesize;
+    }
+    const int xtiles = (w + T - 1) / T, ytiles = (h + T - 1) / T;
+    if (tile1 < 0) tile1 = xtiles * ytiles;
+    if (tile0 < 0 || tile1 > xtiles * ytiles || tile0 >= tile1) return fail(RSR_E_ARG, "tile range outside the image");
     Lane* L = acquire_lane();
+    // Whatever way this call ends, nothing of it may still be in flight when the lane -- and with it the caller's `in` / `out`
+    // -- is handed back: a HIP failure half way must not turn into a use-after-free of the lane buffers by the next caller.
     struct Release
     {
         Engine* e;
         Lane* l;
-        ~Release() { e->release_lane(l); }
+        bool done_recorded = false;
+        ~Release()
+        {
+            if (l->copy) (void)hipStreamSynchronize(l->copy);
+            if (done_recorded) (void)hipEventSynchronize(l->ev_done);
+            e->release_lane(l);
+        }
     } guard{this, L};
     HIP_TRY(hipSetDevice(device));
     if (!L->copy)
@@ -937,37 +1009,60 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     HIP_TRY(hipEventRecord(L->ev_in, L->copy));
 
     // ---- network ----
-    size_t out_off = 0, nout = nout_full, half_rows = 0;
+    size_t half_rows = 0;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!loaded) return fail(RSR_E_STATE, "process before load");
-        if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
+        if (!loaded || scale != 4 || tilesize != T)
+            return fail(RSR_E_STATE, "context parameters changed while the call was in flight"); // (the guard drains the upload)
         HIP_TRY(hipStreamWaitEvent(stream, L->ev_in, 0));
-        const int ytiles = (h + tilesize - 1) / tilesize;
-        if (row1 < 0) row1 = ytiles;
-        if (row0 < 0 || row1 > ytiles || row0 >= row1)
-        {
-            (void)hipStreamSynchronize(L->copy);
-            return fail(RSR_E_ARG, "tile row range outside the image");
-        }
-        // output rows of the tile rows [row0, row1): a contiguous byte range of the HWC image
-        const size_t rowbytes = size_t(w) * scale * c;
-        out_off = size_t(row0) * tilesize * scale * rowbytes;
-        nout = size_t(std::min(row1 * tilesize, h) - row0 * tilesize) * scale * rowbytes;
-        rc = enqueue_image(L->d_in.p, w, h, c, L->d_out.p, stream, row0, row1, L->ev_half, &half_rows);
+        rc = enqueue_image(L->d_in.p, w, h, c, L->d_out.p, stream, tile0, tile1, L->ev_half, &half_rows);
         if (rc != RSR_OK)
         {
-            (void)hipStreamSynchronize(L->copy);
+            (void)hipStreamSynchronize(stream); // kernels of this call that did get enqueued use the lane buffers
             return rc;
         }
         HIP_TRY(hipEventRecord(L->ev_done, stream));
+        guard.done_recorded = true;
     }
 
     // ---- download ----
-    // When the engine split the 4x tail, the first `half_rows` output rows are complete at ev_half: they travel while the second
-    // part is still being computed.
+    const size_t rowbytes = size_t(w) * scale * c; // one output row
+    auto yof = [&](int tr) { return size_t(std::min(tr * T, h)) * scale; };  // first output row of tile row tr
+    auto xof = [&](int tc) { return size_t(std::min(tc * T, w)) * scale * c; }; // byte column of tile column tc
+    const int r0 = tile0 / xtiles, c0 = tile0 % xtiles, r1 = (tile1 - 1) / xtiles, c1 = (tile1 - 1) % xtiles + 1; // last tile = (r1, c1 - 1)
+    if (c0 != 0 || c1 != xtiles)
+    { // general tile range: up to three rectangles, straight into the caller's buffer (pinned or not)
+        HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_done, 0));
+        const char* dsrc = static_cast<const char*>(L->d_out.p);
+        auto rect = [&](size_t y_a, size_t y_b, size_t x_a, size_t x_b) -> hipError_t {
+            if (y_b <= y_a || x_b <= x_a) return hipSuccess;
+            const size_t off = y_a * rowbytes + x_a;
+            return hipMemcpy2DAsync(out + off, rowbytes, dsrc + off, rowbytes, x_b - x_a, y_b - y_a, hipMemcpyDeviceToHost, L->copy);
+        };
+        if (r0 == r1) HIP_TRY(rect(yof(r0), yof(r0 + 1), xof(c0), xof(c1)));
+        else
+        {
+            int full0 = r0, full1 = r1 + 1; // whole tile rows [full0, full1)
+            if (c0 != 0)
+            {
+                HIP_TRY(rect(yof(r0), yof(r0 + 1), xof(c0), rowbytes));
+                full0 = r0 + 1;
+            }
+            if (c1 != xtiles)
+            {
+                HIP_TRY(rect(yof(r1), yof(r1 + 1), 0, xof(c1)));
+                full1 = r1;
+            }
+            HIP_TRY(rect(yof(full0), yof(full1), 0, rowbytes));
+        }
+        HIP_TRY(hipStreamSynchronize(L->copy));
+        return RSR_OK;
+    }
+    // whole tile rows [r0, r1]: a contiguous byte range of the HWC image.  When the engine split the 4x tail, the first
+    // `half_rows` output rows are complete at ev_half: they travel while the second part is still being computed.
+    const size_t out_off = yof(r0) * rowbytes, nout = (yof(r1 + 1) - yof(r0)) * rowbytes;
     out += out_off;
-    const size_t first = std::min(nout, half_rows * size_t(w) * scale * c);
+    const size_t first = std::min(nout, half_rows * rowbytes);
     const bool pinned_out = is_pinned_host(out);
     if (pinned_out)
     {
@@ -1077,8 +1172,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     int rc = pack_model(m, pk.data(), pk.size(), e);
     if (rc != RSR_OK) return fail(rc, e);
     const PackedConv pc = *reinterpret_cast<const PackedConv*>(pk.data() + sizeof(PackedHeader));
-    const int kv = (kernel_version >= 4) ? 4 : kernel_version; // the layer hook has no fp32 trunk
-    const int pch = kv >= 4 ? 16 : 32;
+    constexpr int pch = plane_ch();
     const int np = int(pc.nplanes) * (32 / pch), nt = int(pc.nt); // input planes (cin padded to a multiple of 32)
     const int npo = nt * (32 / pch);                              // output planes
     const int H = ups ? 2 * h : h, W = ups ? 2 * w : w;
@@ -1125,7 +1219,6 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         a.n0 = np;
         a.lvl_in = 0;
         a.lvl_out = ups ? 1 : 0;
-        a.wpk = static_cast<const char*>(d_w.p) + pc.w_off;
         a.wpk16 = static_cast<const char*>(d_w.p) + pc.w16_off;
         a.bias = reinterpret_cast<const float*>(static_cast<const char*>(d_w.p) + pc.b_off);
         a.lrelu = lrelu;
@@ -1137,7 +1230,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
             {
                 a.res1 = a.src0;
                 a.res1_kind = 1;
-                a.res1_in_acc = kv >= 4 || !(dbg & 4096);
+                a.res1_in_acc = 1;
                 a.res1_coef = 1.f / s1;
             }
             if (res)
@@ -1153,13 +1246,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         a.dims = static_cast<const TileDim*>(d_tab.p);
         a.zeros = zeros.p;
         a.dbg = dbg;
-        if (kv >= 4)
-        {
-            if (!launch_conv_flow(a, nt, num_cu, flow_flags, stream)) rc = fail(RSR_E_STATE, "conv3x3_flow: no variant");
-        }
-        else if (kv == 3 && nt == 1 && launch_conv_ring(a, nt, num_cu, stream)) {}
-        else if (kv >= 2) launch_conv_pipe(a, nt, num_cu, stream);
-        else launch_conv(a, nt, use_dma, stream);
+        if (!launch_conv_flow(a, nt, num_cu, flow_flags, stream)) rc = fail(RSR_E_STATE, "conv3x3_flow: no variant");
         he = hipStreamSynchronize(stream);
         if (he == hipSuccess) he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpy(hout.data(), d_out.p, hout.size() * 2, hipMemcpyDeviceToHost);

@@ -40,8 +40,9 @@ struct DevBuf
 struct Plan
 {
     int w = 0, h = 0, c = 0, T = 0, P = 0, tta = 0;
-    int row0 = 0, row1 = 0; // tile rows [row0, row1) of the image this plan covers (multi-GPU tile sharding)
+    int tile0 = 0, tile1 = 0; // tiles [tile0, tile1) of the image's tile grid, row-major (multi-GPU tile sharding)
     long long budget_mb = 0;
+    bool trim = true;
     long long cap_px = 0; // slot capacity in LR pixels
     int max_tw = 0, max_th = 0;
     struct Batch
@@ -52,6 +53,7 @@ struct Plan
         std::vector<WorkItem> items[3];
         std::vector<int> item_start[3]; // first item of every slot (+ end): items are sorted by slot
         double px[3] = {0, 0, 0}; // sum over slots of H*W at each level (for FLOP accounting)
+        int trim4 = 0;            // prepadding * scale when the tables were trimmed to the kept rectangle (make_items), else 0
         // device copies
         BaseTile* d_tiles = nullptr;
         TileDim* d_dims = nullptr;
@@ -102,18 +104,16 @@ struct Engine
     int tta = 0;
     int scale = 4, tilesize = 200, prepadding = 10;
     bool loaded = false;
-    bool trunk_fp32 = false; // residual trunk storage: fp16 like the reference Vulkan path (realsr.cpp:45); true = extra fp32 copy (kernels 1-3)
-    bool use_dma = true;
     bool bgr = false; // pixel order of the caller's images: BGR(A) like the reference's Windows/WIC path (realsr.cpp:188-206,497-515)
-    // 4: conv3x3_flow on 16-channel planes (default); 3: conv3x3_ring + conv3x3_pipe, 2: conv3x3_pipe, 1: conv3x3_mfma (32-channel planes)
-    int kernel_version = 4;
     int flow_flags = 0; // launch_conv_flow flags
     int num_cu = 256;
     int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
+    bool trim_tail = true; // leave out the blocks / rows behind the trunk that only feed cropped output pixels (engine.cpp: tail_margin)
     bool alternate_order = true; // odd convs walk the work items backwards: they start on the data the previous conv touched last
     int trace_conv = -1; // conv index whose launch records s_memtime stamps into trace_buf (profiling only)
     DevBuf trace_buf;
     long long max_workspace_mb = 65536;
+    long long ws_clamp_bytes = -1; // set after a workspace allocation failed: the next plans stay below it (-1 = none)
     int tail_group_slots = 0; // slots per launch group of the 2x / 4x convs (0 = the whole batch at once), see run_network
     int max_lanes = 4;
     size_t chunk_bytes = size_t(16) << 20; // download chunk for pageable destinations
@@ -123,14 +123,12 @@ struct Engine
 
     // model
     std::vector<PackedConv> convs;
-    bool has_w32 = false;
     DevBuf blob; // packed weights on device
     DevBuf zeros;
 
-    // workspace (one allocation per buffer kind), layout = (plane channels, slot capacity)
-    int ws_plane_ch = 0;
+    // workspace (one allocation per buffer kind), layout = slot capacity
     long long ws_cap_px = 0;
-    DevBuf b_in, b_fea, b_rdb[3], b_t32, b_r32, b_up1, b_up2, b_hr, b_out3;
+    DevBuf b_in, b_fea, b_rdb[3], b_up1, b_up2, b_hr, b_out3;
 
     // plans, most recently used first
     std::list<Plan> plans;
@@ -167,25 +165,26 @@ struct Engine
     // d_in/d_out on this device.  user_stream == nullptr: returns when the output is complete (sync) or enqueued (!sync);
     // otherwise ordered after / before the work of user_stream, asynchronous.
     int process_device(const void* d_in, int w, int h, int c, void* d_out, hipStream_t user_stream, bool sync);
-    // row0/row1: tile rows [row0, row1) only (row1 < 0: all); `out` is always the full (4w x 4h x c) image, only the rows of
+    // tile0/tile1: tiles [tile0, tile1) of the row-major tile grid only (tile1 < 0: all); `out` is always the full (4w x 4h x c) image,
+    // only the output rectangles of
     // those tiles are written
-    int process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, int row0 = 0, int row1 = -1);
+    int process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, int tile0 = 0, int tile1 = -1);
     int net_forward(const uint16_t* in, int w, int h, uint16_t* out);
     // out = act(conv + b); with s1 != 0: v = s1*(conv + b) [+ in[0:cout] when own_res] [, v = s2*v + res when res]
     int conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout, int lrelu,
                   uint16_t* out, float s1 = 0.f, int own_res = 0, const uint16_t* res = nullptr, float s2 = 1.f);
 
     // ---- internals (call with `mu` held unless noted) ----
-    int plane_ch() const { return (kernel_version >= 4 && !trunk_fp32) ? 16 : 32; }
-    int eff_kernel() const { return (kernel_version >= 4 && trunk_fp32) ? 3 : kernel_version; }
+    static constexpr int plane_ch() { return kPlaneCh; }
     int ensure(DevBuf& b, size_t bytes);
     int ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool layout_changed, bool zero_all, hipStream_t st);
-    int get_plan(int w, int h, int c, int row0, int row1, Plan*& out);
+    int get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out);
+    void free_workspace(hipStream_t st);
     int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
     int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out = nullptr, int fused_out_w = 0, int split_slot = 0,
                     hipEvent_t ev_half = nullptr);
     int launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st);
-    int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int row0 = 0, int row1 = -1,
+    int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int tile0 = 0, int tile1 = -1,
                       hipEvent_t ev_half = nullptr, size_t* half_rows = nullptr);
     void mark_begin(hipStream_t st);
     void mark(int cls, double flops, double bytes, hipStream_t st, int conv_index = -1);
@@ -202,3 +201,9 @@ struct Engine
 const char* last_error(); // message of the calling thread's last failure
 
 } // namespace rsr
+
+// The opaque context of the C-ABI (include/realsr_hip.h): ONE definition for every translation unit.
+struct rsr_ctx
+{
+    rsr::Engine e;
+};

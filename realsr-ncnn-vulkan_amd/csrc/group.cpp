@@ -1,4 +1,4 @@
-// group.cpp -- several GPUs of one node behind the C-ABI: rsr_create_group / rsr_process_rows / rsr_process_group.
+// group.cpp -- several GPUs of one node behind the C-ABI: rsr_create_group / rsr_process_tiles / rsr_process_rows / rsr_process_group.
 //
 // The reference creates one RealSR per GPU and lets every one of them re-read x4.bin (main.cpp:778-791).  Here the model is
 // parsed, validated and packed ONCE; the blob is uploaded to the first GPU and reaches the others through ONE RCCL
@@ -17,11 +17,6 @@
 #include "engine.h"
 
 using namespace rsr;
-
-struct rsr_ctx
-{
-    Engine e;
-};
 
 namespace {
 
@@ -123,6 +118,13 @@ extern "C" {
 int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, const char* parampath, const char* modelpath)
 {
     if (!out || !gpuids || n < 1 || !parampath || !modelpath) return Engine::fail(RSR_E_ARG, "bad arguments");
+    // the calling thread's current device is the caller's business (a host application such as PyTorch relies on it)
+    struct RestoreDevice
+    {
+        int prev = -1;
+        RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+        ~RestoreDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } restore_device;
     for (int i = 0; i < n; i++) out[i] = nullptr;
     for (int i = 0; i < n; i++)
         for (int j = 0; j < i; j++)
@@ -132,8 +134,8 @@ int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, cons
     std::string err;
     int rc = load_model(parampath, modelpath, m, err);
     if (rc != RSR_OK) return Engine::fail(rc, err);
-    std::vector<unsigned char> blob(packed_size(m, false));
-    rc = pack_model(m, blob.data(), blob.size(), err, false);
+    std::vector<unsigned char> blob(packed_size(m));
+    rc = pack_model(m, blob.data(), blob.size(), err);
     if (rc != RSR_OK) return Engine::fail(rc, err);
     auto destroy_all = [&]() {
         for (int i = 0; i < n; i++)
@@ -201,28 +203,73 @@ int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, cons
 
 const char* rsr_group_transport(void) { return g_transport.c_str(); }
 
+int rsr_process_tiles(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out, int tile_begin, int tile_end)
+{
+    if (!ctx) return RSR_E_ARG;
+    return ctx->e.process_host(in, w, h, c, out, tile_begin, tile_end);
+}
+
 int rsr_process_rows(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out, int tile_row_begin, int tile_row_end)
 {
     if (!ctx) return RSR_E_ARG;
-    return ctx->e.process_host(in, w, h, c, out, tile_row_begin, tile_row_end);
+    if (w < 1 || h < 1 || tile_row_begin < 0 || tile_row_end <= tile_row_begin) return Engine::fail(RSR_E_ARG, "tile row range outside the image");
+    int T;
+    {
+        std::lock_guard<std::mutex> lk(ctx->e.mu);
+        T = ctx->e.tilesize;
+    }
+    const int xtiles = (w + T - 1) / T, ytiles = (h + T - 1) / T;
+    if (tile_row_end > ytiles) return Engine::fail(RSR_E_ARG, "tile row range outside the image");
+    return ctx->e.process_host(in, w, h, c, out, tile_row_begin * xtiles, tile_row_end * xtiles);
 }
 
+// One image over n contexts.  The TILES of the grid (not its rows: a 1080p frame at tile 200 has 6 tile rows, the last one 80
+// pixels high -- split by rows it could use 6 of 8 GPUs and wait for the slowest) are dealt in contiguous row-major ranges of
+// equal padded-pixel load (within one tile), each context uploads the image, runs its range and fetches exactly the output
+// rectangles of its tiles into the caller's buffer (realsr.cpp:377-380,458-459,490: tiles read a halo'd window of the
+// immutable input and write disjoint rectangles).
 int rsr_process_group(rsr_ctx* const* ctx, int n, const uint8_t* in, int w, int h, int c, uint8_t* out)
 {
     if (!ctx || n < 1 || !in || !out || w < 1 || h < 1) return Engine::fail(RSR_E_ARG, "bad arguments");
     for (int i = 0; i < n; i++)
         if (!ctx[i]) return Engine::fail(RSR_E_ARG, "null context in group");
-    const int T = ctx[0]->e.tilesize;
-    const int ytiles = (h + T - 1) / T;
-    const int parts = std::min(n, ytiles);
+    // every member maps a tile range to pixels with its OWN parameters: they must agree, or rectangles are written twice / never
+    int T = 0, P = 0, S = 0, tta = 0;
+    for (int i = 0; i < n; i++)
+    {
+        std::lock_guard<std::mutex> lk(ctx[i]->e.mu);
+        const Engine& e = ctx[i]->e;
+        if (i == 0) { T = e.tilesize; P = e.prepadding; S = e.scale; tta = e.tta; }
+        else if (e.tilesize != T || e.prepadding != P || e.scale != S || e.tta != tta)
+            return Engine::fail(RSR_E_ARG, "group members carry different parameters (tilesize / prepadding / scale / tta)");
+    }
+    const int xtiles = (w + T - 1) / T, ytiles = (h + T - 1) / T, ntiles = xtiles * ytiles;
+    const int parts = std::min(n, ntiles);
     if (parts == 1) return ctx[0]->e.process_host(in, w, h, c, out);
+    // boundaries by padded tile area: share i ends at the first tile where the running load reaches (i+1)/parts of the total
+    std::vector<long long> cum(size_t(ntiles) + 1, 0);
+    for (int t = 0; t < ntiles; t++)
+    {
+        const int yi = t / xtiles, xi = t % xtiles;
+        const long long tw = std::min((xi + 1) * T, w) - xi * T + 2 * P, th = std::min((yi + 1) * T, h) - yi * T + 2 * P;
+        cum[size_t(t) + 1] = cum[size_t(t)] + tw * th;
+    }
+    std::vector<int> bound(size_t(parts) + 1, 0);
+    bound[size_t(parts)] = ntiles;
+    for (int i = 1; i < parts; i++)
+    {
+        const long long target = cum[size_t(ntiles)] * i / parts;
+        int b = int(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        b = std::max(b, bound[size_t(i) - 1] + 1);      // every share gets at least one tile
+        b = std::min(b, ntiles - (parts - i));          // ... also the ones behind it
+        bound[size_t(i)] = b;
+    }
     std::vector<int> rcs(size_t(parts), RSR_OK);
     std::vector<std::string> errs{size_t(parts)};
     std::vector<std::thread> th;
     for (int i = 0; i < parts; i++)
         th.emplace_back([&, i] {
-            const int r0 = int((long long)ytiles * i / parts), r1 = int((long long)ytiles * (i + 1) / parts);
-            rcs[size_t(i)] = ctx[i]->e.process_host(in, w, h, c, out, r0, r1);
+            rcs[size_t(i)] = ctx[i]->e.process_host(in, w, h, c, out, bound[size_t(i)], bound[size_t(i) + 1]);
             if (rcs[size_t(i)] != RSR_OK) errs[size_t(i)] = rsr::last_error();
         });
     for (auto& t : th) t.join();

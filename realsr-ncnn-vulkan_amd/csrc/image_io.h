@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <cstdint>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,6 +70,7 @@ inline std::string decode_pnm(const std::vector<uint8_t>& f, Image& out)
     const int w = vals[0], h = vals[1], ch = f[1] == '6' ? 3 : 1;
     if (n < 3 || vals[2] != 255 || w < 1 || h < 1 || pos + size_t(w) * h * ch > f.size()) return "unsupported or truncated PNM";
     out.create(w, h, 3);
+    if (out.empty()) return "out of memory";
     for (size_t i = 0; i < size_t(w) * h; i++)
         for (int q = 0; q < 3; q++) out.data()[i * 3 + q] = f[pos + i * ch + (ch == 3 ? q : 0)];
     return "";
@@ -96,9 +98,9 @@ inline std::string load_image(const std::string& path, Image& out)
         uint8_t* px = webpdl::decode(f.data(), f.size(), &w, &h, &c, err);
         if (!px) return err;
         out.create(w, h, c);
-        std::memcpy(out.data(), px, size_t(w) * h * c);
+        if (!out.empty()) std::memcpy(out.data(), px, size_t(w) * h * c);
         webpdl::release(px);
-        return "";
+        return out.empty() ? "out of memory" : "";
     }
     if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return decode_pnm(f, out);
     int w = 0, h = 0, c = 0;
@@ -121,9 +123,9 @@ inline std::string load_image(const std::string& path, Image& out)
         return "unsupported channel count";
     }
     out.create(w, h, want);
-    std::memcpy(out.data(), px, size_t(w) * h * want);
+    if (!out.empty()) std::memcpy(out.data(), px, size_t(w) * h * want);
     stbi_image_free(px);
-    return "";
+    return out.empty() ? "out of memory" : "";
 }
 
 inline void put_chunk(std::vector<uint8_t>& o, const char* type, const uint8_t* d, size_t len)
@@ -133,7 +135,14 @@ inline void put_chunk(std::vector<uint8_t>& o, const char* type, const uint8_t* 
     const size_t start = o.size();
     o.insert(o.end(), type, type + 4);
     if (len) o.insert(o.end(), d, d + len);
-    be(uint32_t(crc32(0L, &o[start], uInt(4 + len))));
+    uLong crc = crc32(0L, &o[start], 4); // zlib's length argument is 32 bits: feed long chunks in pieces
+    for (size_t off = 0; off < len;)
+    {
+        const size_t n = std::min(len - off, size_t(1) << 30);
+        crc = crc32(crc, &o[start + 4 + off], uInt(n));
+        off += n;
+    }
+    be(uint32_t(crc));
 }
 
 inline std::string save_png(const std::string& path, const Image& im, int level = 2)
@@ -154,7 +163,13 @@ inline std::string save_png(const std::string& path, const Image& im, int level 
     uint8_t ihdr[13] = {uint8_t(im.w >> 24), uint8_t(im.w >> 16), uint8_t(im.w >> 8), uint8_t(im.w), uint8_t(im.h >> 24), uint8_t(im.h >> 16),
                         uint8_t(im.h >> 8), uint8_t(im.h), 8, uint8_t(im.elempack == 4 ? 6 : 2), 0, 0, 0};
     put_chunk(o, "IHDR", ihdr, 13);
-    put_chunk(o, "IDAT", comp.data(), clen);
+    // a chunk length is a 31-bit field (PNG 5.3): compressed data beyond that goes into further IDAT chunks
+    const size_t kMaxChunk = size_t(0x7fffffff);
+    for (size_t off = 0; off < size_t(clen) || off == 0; off += kMaxChunk)
+    {
+        put_chunk(o, "IDAT", comp.data() + off, std::min(kMaxChunk, size_t(clen) - off));
+        if (size_t(clen) == 0) break;
+    }
     put_chunk(o, "IEND", nullptr, 0);
     FILE* fp = std::fopen(path.c_str(), "wb");
     if (!fp) return "cannot open output file";

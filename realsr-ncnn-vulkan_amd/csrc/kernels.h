@@ -7,21 +7,18 @@
 namespace rsr {
 
 // ---- activation storage ("planes") -----------------------------------------------------------
-// Every feature tensor lives in HBM as a set of 32-channel planes: plane = [H][W][32] fp16
-// (64 B per pixel, pixels row-major, no border).  A 64-channel tensor = 2 planes, the 192-channel
-// dense-block working set = 6 planes.  Tiles of one batch occupy "slots" at a fixed stride.
-// fp32 residual trunk: [H][W][32] fp32 planes (128 B per pixel).
+// Every feature tensor lives in HBM as a set of 16-channel planes: plane = [guard 64 B | [H][W][16] fp16]
+// (32 B per pixel, pixels row-major, no border).  A 64-channel tensor = 4 planes, the 192-channel
+// dense-block working set = 12 planes.  Tiles of one batch occupy "slots" at a fixed stride.
 //
-// Work decomposition of the conv kernel: one workgroup (256 threads = 4 waves) computes a
-// 16-row x 32-column block of output pixels for all output channels; work items (slot, y0, x0)
-// come from a device table.
+// Work decomposition of the conv kernel: one workgroup computes a 16-row x 32-column block of output
+// pixels for all output channels; work items (slot, y0, x0) come from a device table.
 
 constexpr int kBlkH = 16, kBlkW = 32;          // output block of one workgroup
 constexpr int kPatchH = kBlkH + 2, kPatchW = kBlkW + 2;
 constexpr int kPatchPx = kPatchH * kPatchW;     // 612
-constexpr int kPatchBytes = kPatchPx * 64;      // 39168
 constexpr int kGuard = 64;                      // zero bytes in front of every conv-input plane (LDS-DMA source for padding)
-constexpr int kPatchLds = 39936;                // LDS bytes reserved for the patch: 39 wave-sized (1 KiB) LDS-DMA pieces
+constexpr int kPlaneCh = 16;                    // channels per plane
 
 struct WorkItem // 32 bytes: one aligned 2 x 16-byte fetch gives a workgroup everything about its block
 {
@@ -51,21 +48,22 @@ struct ConvArgs
     int n0, n1;
     int lvl_in;  // input resolution = LR << lvl_in
     int lvl_out; // output resolution = LR << lvl_out (lvl_out == lvl_in + 1 for the nearest-x2 fused convs)
-    // weights: packed LDS images, one per 32-cin chunk; bias fp32 [NT*32]
-    const void* wpk;   // kernels 1-3 (32-channel planes): LDS images [chunk of 32 cin][9 taps][NT*32 cout][32 cin]
-    const void* wpk16; // conv3x3_flow (16-channel planes): LDS images [plane of 16 cin][9 taps][NT*32 cout][16 cin]
+    // weights: packed LDS images [plane of 16 cin][9 taps][NT*32 cout][16 cin]; bias fp32 [NT*32]
+    const void* wpk16;
     const float* bias;
     int lrelu; // LeakyReLU(0.2) on (acc + bias)
-    // residual stages: v = v*s + r  (r fp32 plane or fp16 plane)
+    // Output pixels closer than `margin` to the tile border (at this conv's output level) are never read by anything that
+    // reaches the cropped output rectangle (engine.cpp: tail_margins): MFMA waves whose four rows lie wholly inside that frame
+    // skip their block like rows below the tile.  0 = every pixel is needed.
+    int margin;
+    // residual stages: v = v*s + r  (r = fp16 planes)
     PlaneSrc res1, res2;
-    int res1_kind, res2_kind; // 0 none, 1 fp16 planes, 2 fp32 planes
+    int res1_kind, res2_kind; // 0 none, 1 fp16 planes
     float s1, s2;
-    int res1_in_acc;  // res1 == input planes 0,1 of this conv (fp16): conv3x3_pipe<2,*,2> adds it as an identity tap, coefficient
-    float res1_coef;  // 1/s1 (must be exact in fp16); kernels that ignore the flag still read res1
+    int res1_in_acc;  // res1 == the first planes of this conv's own input: added as an identity tap on the matrix pipe, coefficient
+    float res1_coef;  // 1/s1 (must be exact in fp16)
     // outputs (any may be null)
-    PlaneSrc out16;  // fp16 planes (NT planes)
-    PlaneSrc out32a; // fp32 planes
-    PlaneSrc out32b;
+    PlaneSrc out16;  // fp16 planes (2*NT planes)
     // conv_last: planar fp16 [3][H][W] per slot
     void* out_planar3;
     long long planar3_slot_stride; // bytes
@@ -82,9 +80,6 @@ struct ConvArgs
     int dbg;           // ablation switches for profiling: 1 skip DMA, 2 skip MFMA, 4 skip epilogue stores, ...  (realsr_hip.h)
 };
 
-void launch_conv(const ConvArgs& a, int nt, bool dma, hipStream_t st);
-void launch_conv_pipe(const ConvArgs& a, int nt, int ncu, hipStream_t st); // persistent wave-specialised variant
-bool launch_conv_ring(const ConvArgs& a, int nt, int ncu, hipStream_t st); // + 3-stage patch ring; false = does not fit (64 output channels)
 // conv_flow.hip: half-stage ring on 16-channel planes.  flags: 1 = two n-tiles per MFMA wave for 64-cout convs, 2 = no deferred epilogue.
 // false = this combination of outputs / residuals is not covered (the engine then reports an error)
 bool launch_conv_flow(const ConvArgs& a, int nt, int ncu, int flags, hipStream_t st);
@@ -112,7 +107,7 @@ struct PreArgs
     void* in_plane; // fp16 plane [th][tw][plane_ch] per slot, channels 0..2 = RGB/255, rest 0
     long long slot_stride;
     int bgr;
-    int plane_ch;   // 32 (round-1 kernels) or 16 (conv3x3_flow)
+    int plane_ch;   // 16
 };
 void launch_preproc_tiles(const PreArgs& a, int max_tw, int max_th, hipStream_t st);
 

@@ -439,22 +439,21 @@ namespace {
 size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 } // namespace
 
-size_t packed_size(const Model& m, bool with_w32)
+size_t packed_size(const Model& m)
 {
     size_t off = align256(sizeof(PackedHeader) + m.convs.size() * sizeof(PackedConv));
     for (const ConvRec& c : m.convs)
     {
         const size_t np = size_t((c.cin + 31) / 32), nt = size_t((c.cout + 31) / 32);
-        if (with_w32) off = align256(off + np * 9 * nt * 32 * 64);
         off = align256(off + nt * 32 * 4);
         off = align256(off + 2 * np * 9 * nt * 32 * 32);
     }
     return off;
 }
 
-int pack_model(const Model& m, void* dst, size_t cap, std::string& err, bool with_w32)
+int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
 {
-    const size_t need = packed_size(m, with_w32);
+    const size_t need = packed_size(m);
     if (cap < need)
     {
         err = "packed blob buffer too small";
@@ -466,7 +465,7 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err, bool wit
     H->magic = kPackedMagic;
     H->version = kPackedVersion;
     H->nconv = uint32_t(m.convs.size());
-    H->flags = with_w32 ? 1u : 0u;
+    H->flags = 0u;
     H->total_bytes = need;
     PackedConv* T = reinterpret_cast<PackedConv*>(base + sizeof(PackedHeader));
     size_t off = align256(sizeof(PackedHeader) + m.convs.size() * sizeof(PackedConv));
@@ -487,25 +486,6 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err, bool wit
             return f32_to_f16(v);
         };
         const int rows = 9 * nt * 32;
-        P.w_off = 0;
-        if (with_w32)
-        {
-            P.w_off = off;
-            uint16_t* W = reinterpret_cast<uint16_t*>(base + off);
-            for (int ck = 0; ck < np; ck++)
-                for (int tap = 0; tap < 9; tap++)
-                    for (int n = 0; n < nt * 32; n++)
-                    {
-                        const int row = tap * nt * 32 + n;
-                        uint16_t* R = W + (size_t(ck) * rows + row) * 32;
-                        for (int slot = 0; slot < 4; slot++)
-                        {
-                            const int pslot = slot ^ ((row >> 2) & 3);
-                            for (int e = 0; e < 8; e++) R[pslot * 8 + e] = wt(n, ck * 32 + slot * 8 + e, tap);
-                        }
-                    }
-            off = align256(off + size_t(np) * rows * 64);
-        }
         P.b_off = off;
         float* B = reinterpret_cast<float*>(base + off);
         for (int n = 0; n < c.cout; n++) B[n] = c.bias[size_t(n)];
@@ -558,12 +538,11 @@ int check_packed(const void* head, size_t head_bytes, size_t total_bytes, std::s
         return RSR_E_FORMAT;
     }
     const PackedHeader* H = static_cast<const PackedHeader*>(head);
-    if (H->magic != kPackedMagic || H->version != kPackedVersion || H->nconv != uint32_t(kNumConvs) || H->total_bytes != total_bytes)
+    if (H->magic != kPackedMagic || H->version != kPackedVersion || H->nconv != uint32_t(kNumConvs) || H->total_bytes != total_bytes || H->flags != 0u)
     {
         err = "packed blob header mismatch (magic / version / conv count / size)";
         return RSR_E_FORMAT;
     }
-    const bool w32 = (H->flags & 1u) != 0;
     const PackedConv* T = reinterpret_cast<const PackedConv*>(static_cast<const unsigned char*>(head) + sizeof(PackedHeader));
     for (int i = 0; i < kNumConvs; i++)
     {
@@ -574,7 +553,6 @@ int check_packed(const void* head, size_t head_bytes, size_t total_bytes, std::s
         bool ok = int(c.cin) == cin && int(c.cout) == cout && int(c.act) == act && c.nplanes == np && c.nt == nt;
         auto inside = [&](uint64_t off, uint64_t size) { return off >= packed_table_bytes() && (off & 255) == 0 && off <= total_bytes && size <= total_bytes - off; };
         ok = ok && inside(c.b_off, nt * 32 * 4) && inside(c.w16_off, 2 * np * 9 * nt * 32 * 32);
-        ok = ok && (w32 ? inside(c.w_off, np * 9 * nt * 32 * 64) : c.w_off == 0);
         if (!ok)
         {
             err = "packed blob conv table corrupt at convolution " + std::to_string(i);

@@ -54,21 +54,18 @@ int read_bin(const std::string& path, Model& m, std::string& err);
 int load_model(const std::string& param, const std::string& bin, Model& m, std::string& err);
 
 // ---- packed blob ---------------------------------------------------------------------------
-// One relocatable byte blob holding every conv's weights in the exact LDS images the MFMA kernels stage:
-//   w16 (conv3x3_flow, 16-channel planes): per conv, per 16-input-channel plane
-//       [tap 0..8][cout row 0..NT*32-1][16 cin] fp16, 32 B per row, the two 16-B slots of a row swapped when (cout>>3)&1
-//   w32 (round-1 kernels conv3x3_ring / _pipe / _mfma, 32-channel planes; kept as second implementations for the
-//       A/B tests): per conv, per 32-input-channel chunk [tap][cout row][32 cin], 64 B per row, the four 16-B slots
-//       XOR-swizzled with ((row_index >> 2) & 3), row_index = tap*NT*32 + cout
+// One relocatable byte blob holding every conv's weights in the exact LDS images the MFMA kernel stages (conv3x3_flow,
+// 16-channel planes): per conv, per 16-input-channel plane
+//     [tap 0..8][cout row 0..NT*32-1][16 cin] fp16, 32 B per row, the two 16-B slots of a row swapped when (cout>>3)&1
 // followed by NT*32 fp32 biases.  Cin is zero-padded to a multiple of 32 (conv_first 3 -> 32: two 16-channel planes,
-// the second all zero), Cout to a multiple of 32 (conv_last 3 -> 32).  pack_model(.., with_w32 = false) leaves the
-// w32 images out (w_off = 0): that is what travels in the multi-GPU broadcast.
+// the second all zero), Cout to a multiple of 32 (conv_last 3 -> 32).  33.5 MB for x4.param: what rsr_load uploads and
+// what the multi-GPU broadcast carries.
 struct PackedHeader
 {
     uint32_t magic;   // 'RSRP'
-    uint32_t version; // 3
+    uint32_t version; // 4
     uint32_t nconv;
-    uint32_t flags;   // bit 0: w32 images present
+    uint32_t flags;   // 0 (version 3 carried the 32-channel images of the round-1 kernels behind bit 0)
     uint64_t total_bytes;
 };
 struct PackedConv
@@ -78,14 +75,14 @@ struct PackedConv
     uint32_t nplanes;       // ceil(cin/32): 32-channel chunks (= half the number of 16-channel planes)
     uint32_t nt;            // ceil(cout/32)
     float slope;
-    uint64_t w_off, b_off;  // byte offsets from blob start (256-B aligned); w_off = 0 when the w32 images are absent
+    uint64_t b_off;         // byte offsets from blob start (256-B aligned)
     uint64_t w16_off;       // 16-channel-plane images
 };
-constexpr uint32_t kPackedVersion = 3;
+constexpr uint32_t kPackedVersion = 4;
 constexpr uint32_t kPackedMagic = 0x50525352u; // "RSRP"
 
-size_t packed_size(const Model& m, bool with_w32 = true);
-int pack_model(const Model& m, void* dst, size_t cap, std::string& err, bool with_w32 = true);
+size_t packed_size(const Model& m);
+int pack_model(const Model& m, void* dst, size_t cap, std::string& err);
 // Full validation of a blob that may come from anywhere (a broadcast, a file): header, every offset + extent inside the
 // blob, and the conv table equal to the canonical RRDBNet schedule (cin/cout/act per index) the engine hard-wires.
 // Only the header + table (first packed_table_bytes() bytes) are dereferenced.

@@ -1,0 +1,99 @@
+"""Oracle references for many tiles at once (test infrastructure): the CPU oracle runs 16 OpenMP threads well and no more
+(oracle.py), the GPU box has 256 hardware threads -- so whole BASELINE frames are checked tile by tile with a pool of
+worker PROCESSES, each holding its own OracleNet.  A 1080p frame at tile 200 (60 tiles, 104 TFLOP of fp32 CPU work) takes
+about half a minute this way.
+
+ref_tiles(pp, bp, [(padded CHW float32 tile, tta)]) -> [uint8 (4*th, 4*tw, 3) of the un-padded rectangle]
+following realsr.cpp:525-838: network on the halo'd tile (x8 dihedral variants under TTA, realsr.cpp:617-724, merged
+(sum) * 0.125), crop prepadding * 4, v * 255 + 0.5, truncate, clamp."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_NET = None
+
+
+def _init(pp, bp, threads):
+    global _NET
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["RSR_NO_TORCH"] = "1"
+    import oracle
+    _NET = oracle.OracleNet(pp, bp)
+    oracle.set_threads(threads)
+
+
+def _one(job):
+    tile, tta, P = job
+    if not tta:
+        o = _NET.forward(np.ascontiguousarray(tile))
+    else:
+        acc = None
+        for k in range(8):  # the 8 dihedral variants and their inverse maps, as tests/test_oracle.py states them independently
+            t = tile
+            if k & 4:
+                t = t.transpose(0, 2, 1)
+            if k & 1:
+                t = t[:, ::-1]
+            if k & 2:
+                t = t[:, :, ::-1]
+            r = _NET.forward(np.ascontiguousarray(t))
+            if k & 2:
+                r = r[:, :, ::-1]
+            if k & 1:
+                r = r[:, ::-1]
+            if k & 4:
+                r = r.transpose(0, 2, 1)
+            acc = r.astype(np.float32) if acc is None else acc + r
+        o = acc * np.float32(0.125)
+    o = o[:, 4 * P:o.shape[1] - 4 * P, 4 * P:o.shape[2] - 4 * P]
+    return np.clip((o * 255.0 + 0.5).astype(np.int32), 0, 255).astype(np.uint8).transpose(1, 2, 0)
+
+
+def ref_tiles(pp, bp, jobs, P=10, threads=16, workers=None):
+    jobs = [(t, tta, P) for (t, tta) in jobs]
+    cpus = os.cpu_count() or 1
+    if workers is None:
+        workers = max(1, min(len(jobs), (cpus * 3 // 4) // threads, 12))
+    threads = max(1, min(threads, cpus))
+    if workers <= 1:
+        _init(pp, bp, threads)
+        return [_one(j) for j in jobs]
+    ctx = mp.get_context("spawn")  # never fork a process that holds a HIP context
+    with ctx.Pool(workers, initializer=_init, initargs=(pp, bp, threads)) as pool:
+        return pool.map(_one, jobs, chunksize=1)
+
+
+def padded_tile(img, x0, y0, tw, th, P=10):
+    """The padded network input of the tile whose un-padded origin is (x0, y0): reflect-101 at the image border
+    (realsr.cpp:613 copy_make_border type 2 == numpy 'reflect'), real neighbours elsewhere.  CHW float32 in [0,1]."""
+    big = np.pad(img, ((P, P), (P, P), (0, 0)), mode="reflect")
+    t = big[y0:y0 + th + 2 * P, x0:x0 + tw + 2 * P, :3]
+    return t.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+
+
+def check_frame_tiles(out, img, pp, bp, T, tiles=None, tta=False, P=10):
+    """Compare the tiles `tiles` (list of (xi, yi); None = every tile of the grid) of the engine's output `out` for `img` at
+    tile size T with the oracle, +-1 uint8.  Returns (tiles checked, fraction of differing bytes)."""
+    h, w = img.shape[:2]
+    xt, yt = (w + T - 1) // T, (h + T - 1) // T
+    if tiles is None:
+        tiles = [(xi, yi) for yi in range(yt) for xi in range(xt)]
+    geo = []
+    for xi, yi in tiles:
+        x0, y0 = xi * T, yi * T
+        geo.append((x0, y0, min(x0 + T, w) - x0, min(y0 + T, h) - y0))
+    refs = ref_tiles(pp, bp, [(padded_tile(img, *g, P=P), tta) for g in geo], P=P)
+    diff = 0
+    total = 0
+    for (x0, y0, tw, th), ref in zip(geo, refs):
+        got = out[4 * y0:4 * (y0 + th), 4 * x0:4 * (x0 + tw), :3].astype(int)
+        d = np.abs(got - ref.astype(int))
+        assert d.max() <= 1, "tile at (%d,%d) %dx%d: max diff %d" % (x0, y0, tw, th, d.max())
+        diff += int((d > 0).sum())
+        total += d.size
+    return len(geo), diff / max(total, 1)

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 import oracle
+import oracle_pool
 import realsr_ncnn_vulkan_amd as R
 from realsr_ncnn_vulkan_amd import synth
 
@@ -140,50 +141,48 @@ def test_pinned_buffers_equal_pageable(sr):
 def test_guards_stay_zero_across_layout_and_slot_changes(paths):
     """A large image lays the workspace out for many slots; a small-cap image re-lays it out with 2 slots; a third image
     with the SAME slot capacity but more slots must not find stale activations where its guards are (conv zero padding
-    reads them).  Compared with a fresh context, byte for byte; both plane layouts (kernel 4: 16-channel, kernel 3: 32)."""
+    reads them).  Compared with a fresh context, byte for byte."""
     imgs = [synth.make_image(41, 150, 120), synth.make_image(42, 40, 20), synth.make_image(43, 100, 20)]
-    for kernel in (4, 3):
-        a = R.RealSR(0)
-        a.load(*paths)
-        a.tilesize = 32
-        a.set_option("kernel", kernel)
-        seq = [a.process(im) for im in imgs]
-        # and back to the first layout
-        again = a.process(imgs[0])
-        a.close()
-        for im, got in zip(imgs, seq):
-            f = R.RealSR(0)
-            f.load(*paths)
-            f.tilesize = 32
-            f.set_option("kernel", kernel)
-            want = f.process(im)
-            f.close()
-            assert (got == want).all(), "kernel %d: image %s differs from a fresh context" % (kernel, im.shape)
-        assert (again == seq[0]).all()
+    a = R.RealSR(0)
+    a.load(*paths)
+    a.tilesize = 32
+    seq = [a.process(im) for im in imgs]
+    # and back to the first layout
+    again = a.process(imgs[0])
+    a.close()
+    for im, got in zip(imgs, seq):
+        f = R.RealSR(0)
+        f.load(*paths)
+        f.tilesize = 32
+        want = f.process(im)
+        f.close()
+        assert (got == want).all(), "image %s differs from a fresh context" % (im.shape,)
+    assert (again == seq[0]).all()
 
 
 # ---- BASELINE configs that had no oracle check ----------------------------------------------------------------------------
-def test_c2_edge_tile_classes_against_oracle(sr, oracle_net):
-    """C2 (1920x1080, tile 200) has four tile shapes: 220x220, 220x100 (last tile row), 140x220 (last column), 140x100
-    (corner).  One tile of each edge class against the oracle network, +-1 uint8."""
+def test_c2_every_tile_against_oracle(sr, paths):
+    """C2 (1920x1080, tile 200): ALL 60 tiles -- 45 x 220x220, 9 x 220x100 (last tile row), 5 x 140x220 (last column), the
+    140x100 corner -- against the oracle network, +-1 uint8 (a pool of oracle processes, tests/oracle_pool.py)."""
     sr.tilesize = 200
     img = synth.make_image(1235, 1920, 1080)
     out = sr.process(img)
-    check_tile(out, img, oracle_net, 600, 1000, 200, 80)    # 220 x 100
-    check_tile(out, img, oracle_net, 1800, 400, 120, 200)   # 140 x 220
-    check_tile(out, img, oracle_net, 1800, 1000, 120, 80)   # 140 x 100
+    n, frac = oracle_pool.check_frame_tiles(out, img, *paths, T=200)
+    assert n == 60 and frac < 0.15
+    print("C2: 60 tiles within +-1, %.2f %% of the bytes differ" % (100 * frac))
 
 
-def test_c3_tiles_against_oracle_and_batching(sr, oracle_net):
-    """C3 (3840x2160, tile 400): the default 64 GiB workspace budget splits the 60 tiles into 2 batches.  One interior
-    420x420 tile and the 260x180 corner slot against the oracle; the whole frame again with a 200 GiB budget (1 batch)
-    must be byte-identical (batches are an implementation detail)."""
+def test_c3_tiles_against_oracle_and_batching(sr, paths):
+    """C3 (3840x2160, tile 400): the default 64 GiB workspace budget splits the 60 tiles into 2 batches.  Six tiles -- two
+    interior 420x420 (one per batch), a 420x180 and a 260x420 edge tile, the tiles around the batch seam and the 260x180
+    corner -- against the oracle; the whole frame again with a 200 GiB budget (1 batch) must be byte-identical (batches
+    are an implementation detail)."""
     sr.tilesize = 400
     img = synth.make_image(1236, 3840, 2160)
     out = sr.process(img)
     assert out.shape == (8640, 15360, 3)
-    check_tile(out, img, oracle_net, 1200, 800, 400, 400)   # interior 420 x 420
-    check_tile(out, img, oracle_net, 3600, 2000, 240, 160)  # corner 260 x 180
+    n, frac = oracle_pool.check_frame_tiles(out, img, *paths, T=400, tiles=[(3, 2), (0, 0), (6, 5), (9, 1), (9, 5), (4, 3)])
+    assert n == 6 and frac < 0.15
     sr.set_option("max_workspace_mb", 200 * 1024)
     try:
         one = sr.process(img)
@@ -193,19 +192,52 @@ def test_c3_tiles_against_oracle_and_batching(sr, oracle_net):
     assert (sr.process(img) == out).all()  # determinism
 
 
-def test_c5_tta_at_tile_200_against_oracle(paths, oracle_net):
-    """C5's code path: TTA x8 at tile 200 on an image whose grid has all four tile shapes (non-square edge tiles: the 4+4
-    transposed-shape slots of engine.cpp / realsr.cpp:251-258).  Whole image against the oracle's TTA path, +-1 uint8."""
+def test_c5_tta_against_oracle(paths, oracle_net):
+    """C5 (1080p, tile 200, -x): TTA x8 -- 4 + 4 transposed-shape slots for the non-square edge tiles (engine.cpp /
+    realsr.cpp:251-258).  A 260x230 image whose grid has all four tile shapes against the oracle's own TTA path (whole image),
+    then the real 1080p frame: one tile of each of the four shapes against an independent statement of the 8 dihedral passes
+    (every tile with RSR_SLOW_TESTS=1: 480 network evaluations on the CPU, a few minutes)."""
     s = R.RealSR(0, tta_mode=True)
     s.load(*paths)
     s.tilesize = 200
     img = synth.make_image(1239, 260, 230)
     got = s.process(img)
-    s.close()
     ref = oracle_net.process(img, 200, tta=True)
     d = np.abs(got.astype(int) - ref.astype(int))
     assert d.max() <= 1
     assert (d > 0).mean() < 0.15
+    big = synth.make_image(1239, 1920, 1080)
+    out = s.process(big)
+    s.close()
+    tiles = None if os.environ.get("RSR_SLOW_TESTS") == "1" else [(4, 2), (2, 5), (9, 3), (9, 5)]
+    n, frac = oracle_pool.check_frame_tiles(out, big, *paths, T=200, tiles=tiles, tta=True)
+    assert n == (60 if tiles is None else 4) and frac < 0.15
+
+
+def test_engine_options_do_not_change_the_bytes(paths, sr):
+    """Scheduling / staging knobs (include/realsr_hip.h: rsr_set_option) are implementation details: tail launch groups,
+    work-item order, one lane, single-threaded staging copies, small download chunks, no dead-output elimination, rows below
+    the tile computed, small tile batches -- every one must reproduce the default configuration's bytes, RGB, RGBA and TTA."""
+    imgs = [synth.make_image(61, 150, 100), synth.make_image(62, 70, 90, 4)]
+    sr.tilesize = 32
+    want = [sr.process(im) for im in imgs]
+    t = R.RealSR(0, tta_mode=True)
+    t.load(*paths)
+    t.tilesize = 32
+    want_tta = t.process(imgs[0])
+    knobs = [("tail_group", 1, 0), ("tail_group", 3, 0), ("alternate_order", 0, 1), ("max_lanes", 1, 4), ("copy_threads", 1, 4), ("chunk_mb", 1, 16),
+             ("trim", 0, 1), ("dbg", 32, 0), ("dbg", 8192, 0), ("dbg", 16384, 0), ("flow_flags", 3, 0), ("max_workspace_mb", 64, 65536), ("num_cu", 64, 256)]
+    try:
+        for key, val, default in knobs:
+            for ctx, ims, refs in ((sr, imgs, want), (t, imgs[:1], [want_tta])):
+                ctx.set_option(key, val)
+                try:
+                    for im, ref in zip(ims, refs):
+                        assert (ctx.process(im) == ref).all(), (key, val, im.shape, ctx.tta_mode)
+                finally:
+                    ctx.set_option(key, default)
+    finally:
+        t.close()
 
 
 def test_raw_fp32_bin_with_unrepresentable_weights(tmp_path):
@@ -239,25 +271,28 @@ def test_corrupt_blob_is_refused_and_state_survives(paths, sr):
     sr.tilesize = 32
     img = synth.make_image(8, 40, 30)
     want = sr.process(img)
-    blob = R.model_pack(*paths, with_w32=False)
+    blob = R.model_pack(*paths)
     rec = np.dtype([("cin", "<u4"), ("cout", "<u4"), ("act", "<u4"), ("nplanes", "<u4"), ("nt", "<u4"),
-                    ("slope", "<f4"), ("w_off", "<u8"), ("b_off", "<u8"), ("w16_off", "<u8")])
+                    ("slope", "<f4"), ("b_off", "<u8"), ("w16_off", "<u8")])
+    assert rec.itemsize == 40
     for field, value in (("w16_off", blob.size - 256), ("cin", 128), ("nt", 2), ("b_off", blob.size + 4096)):
         bad = blob.copy()
-        table = bad[24:24 + 351 * 48].view(rec)
+        table = bad[24:24 + 351 * 40].view(rec)
         table[field][7] = value
         with pytest.raises(R.RealSRError) as e:
             sr.load_packed(bad)
         assert e.value.code == R.RSR_E_FORMAT, field
         assert (sr.process(img) == want).all(), "a refused blob must not disturb the loaded model"
-    # the slim blob itself loads and gives the same bytes; the round-1 kernels refuse it (no 32-channel images)
+    old_version = blob.copy()
+    old_version[4:8].view("<u4")[0] = 3  # a blob of the previous layout (with the round-1 weight images) is refused, not misread
+    with pytest.raises(R.RealSRError) as e:
+        sr.load_packed(old_version)
+    assert e.value.code == R.RSR_E_FORMAT
+    # the blob itself loads and gives the same bytes as rsr_load
     s2 = R.RealSR(0)
     s2.load_packed(blob)
     s2.tilesize = 32
     assert (s2.process(img) == want).all()
-    s2.set_option("kernel", 3)
-    with pytest.raises(R.RealSRError):
-        s2.process(img)
     s2.close()
 
 
@@ -304,8 +339,10 @@ def test_bgr_pixel_order(sr, paths):
 
 # ---- several GPUs: group creation, tile-row sharding of one image ------------------------------------------------------
 def test_tile_rows_and_group_processing_equal_the_full_image(paths):
-    """one large image split by tile rows.  Two contexts (both on GPU 0 here) each process a disjoint range of
-    tile rows into ONE output buffer; rsr_process_group does the same on its own threads.  Bytes identical to one call."""
+    """one large image split over contexts.  Two contexts (both on GPU 0 here) each process a disjoint range of
+    tile rows / of tiles into ONE output buffer; rsr_process_group deals the TILES (contiguous row-major ranges of equal
+    load, rectangles fetched with 2-D copies) on its own threads.  Bytes identical to one call for 2 / 3 / 5 / 8 shares --
+    ranges that start and end in the middle of a tile row included."""
     a, b = R.RealSR(0), R.RealSR(0)
     for s in (a, b):
         s.load(*paths)
@@ -317,12 +354,36 @@ def test_tile_rows_and_group_processing_equal_the_full_image(paths):
     assert (out[:2 * 32 * 4] == want[:2 * 32 * 4]).all() and (out[2 * 32 * 4:] == 0).all()
     b.process_rows(img, out, 2, 5)
     assert (out == want).all()
-    assert (R.process_group([a, b], img) == want).all()
-    assert (R.process_group([a], img) == want).all()
+    # tile ranges: [0,4) = row 0 + the first tile of row 1; [4,5) one tile in the middle of a row; [5,13) tail of row 1, rows 2-3,
+    # head of row 4; [13,15) the rest.  Every call may only touch the rectangles of its own tiles.
+    out = np.zeros_like(want)
+    mask = np.zeros(want.shape[:2], dtype=bool)
+    for (t0, t1), ctx in zip(((4, 5), (0, 4), (13, 15), (5, 13)), (a, b, a, b)):
+        ctx.process_tiles(img, out, t0, t1)
+        for t in range(t0, t1):
+            yi, xi = divmod(t, 3)
+            mask[yi * 128:min((yi + 1) * 32, 150) * 4, xi * 128:min((xi + 1) * 32, 70) * 4] = True
+        assert (out[mask] == want[mask]).all() and (out[~mask] == 0).all(), (t0, t1)
+    assert mask.all()
+    pinned = R.PinnedArray(want.shape)
+    pinned.array[:] = 0
+    b.process_tiles(img, pinned.array, 2, 11)  # rectangles into pinned memory
+    a.process_tiles(img, pinned.array, 0, 2)
+    a.process_tiles(img, pinned.array, 11, 15)
+    assert (pinned.array == want).all()
+    pinned.free()
+    for parts in (1, 2, 3, 5, 8, 20):
+        ctxs = [(a, b)[i % 2] for i in range(parts)]
+        assert (R.process_group(ctxs, img) == want).all(), parts
     rgba = synth.make_image(56, 40, 100, 4)
-    assert (R.process_group([a, b], rgba) == a.process(rgba)).all()
+    assert (R.process_group([a, b, a], rgba) == a.process(rgba)).all()
+    for bad in ((3, 9), (7, 7), (-1, 2)):
+        with pytest.raises(R.RealSRError) as e:
+            (a.process_rows if bad == (3, 9) else a.process_tiles)(img, out, *bad)
+        assert e.value.code == R.RSR_E_ARG
+    b.tilesize = 48  # members that disagree about the tile grid would write rectangles twice / never: refused
     with pytest.raises(R.RealSRError) as e:
-        a.process_rows(img, out, 3, 9)
+        R.process_group([a, b], img)
     assert e.value.code == R.RSR_E_ARG
     a.close()
     b.close()
@@ -364,15 +425,31 @@ def test_create_group(paths):
 
 # ---- bench.py's multi-rank control flow, executed on ONE gpu (the driver's 8-GPU run is the first real one otherwise) ----------
 def test_bench_multirank_control_flow_on_one_gpu(tmp_path):
-    env = dict(os.environ, RSR_BENCH_SAME_GPU="1", RSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    """`python bench.py --gpus 2` with no torch.distributed environment (the driver's command shape) must start two ranks itself
+    and report n_gpus == 2; RSR_BENCH_SAME_GPU puts both on cuda:0 over gloo.  Behind the rank run, rank 0 runs the product's
+    own multi-GPU path (group mode: contexts + proc threads on a shared queue + rsr_process_group) in a child process."""
+    env = dict(os.environ, RSR_BENCH_SAME_GPU="1", RSR_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert "2 ranks" in j["config"]["parallelism"]
+    g = j["group_mode"]
+    assert g.get("value"), g
+    assert g["n_gpus"] == 2 and sum(g["config"]["frames_per_gpu"]) == g["frames"]
+    assert g["single_image_over_group"]["bytes_equal_single_context"] is True
+    # the driver's own launch shape (torch.distributed.run around the script) still works, and a world size that does not match
+    # --gpus is refused instead of being reported as something else
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--no-host", "--no-group"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 2
 
 
 @pytest.mark.gpu

@@ -90,58 +90,54 @@ def test_error_codes(model_dir, tmp_path):
 
 
 def test_packed_blob_layout(model_dir, weights):
-    """Un-swizzle the packed LDS images (16-channel-plane images of conv3x3_flow and the 32-channel images of the round-1
-    kernels) and compare with the OIHW weights; the broadcast blob (with_w32=False) carries only the former."""
+    """Un-swizzle the packed LDS images (16-channel-plane images of conv3x3_flow) and compare with the OIHW weights; the blob
+    is what rsr_load uploads and what the multi-GPU broadcast carries."""
     pp, bp = os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin")
-    blob = R.model_pack(pp, bp)
-    slim = R.model_pack(pp, bp, with_w32=False)
-    assert slim.size < 0.52 * blob.size and 33e6 < slim.size < 34.5e6  # 33.5 MB: what one RCCL broadcast moves
+    bl = R.model_pack(pp, bp)
+    assert 33e6 < bl.size < 34.5e6  # 33.5 MB: what one RCCL broadcast moves
     rec = np.dtype([("cin", "<u4"), ("cout", "<u4"), ("act", "<u4"), ("nplanes", "<u4"), ("nt", "<u4"),
-                    ("slope", "<f4"), ("w_off", "<u8"), ("b_off", "<u8"), ("w16_off", "<u8")])
-    assert rec.itemsize == 48
+                    ("slope", "<f4"), ("b_off", "<u8"), ("w16_off", "<u8")])
+    assert rec.itemsize == 40
     specs = synth.conv_specs()
-    for bl, full in ((blob, True), (slim, False)):
-        magic, version, nconv, flags = np.frombuffer(bl[:16], np.uint32)
-        assert magic == 0x50525352 and version == 3 and nconv == 351 and flags == (1 if full else 0)
-        assert int(np.frombuffer(bl[16:24], np.uint64)[0]) == bl.size
-        table = np.frombuffer(bl[24:24 + 351 * 48], rec)
-        for i in (0, 1, 4, 5, 346, 349, 350):
-            t = table[i]
-            cin, cout, act = specs[i]
-            assert (t["cin"], t["cout"], t["act"]) == (cin, cout, act)
-            np_, nt = (cin + 31) // 32, (cout + 31) // 32
-            assert (t["nplanes"], t["nt"]) == (np_, nt)
-            rows = 9 * nt * 32
-            W, b = weights[i]
-            Wp = np.zeros((nt * 32, np_ * 32, 3, 3), np.float32)
-            Wp[:cout, :cin] = W
-            if full:
-                img = np.frombuffer(bl[int(t["w_off"]):int(t["w_off"]) + np_ * rows * 64], np.float16).reshape(np_, rows, 4, 8)
-                for ck in range(np_):
-                    for row in (0, 5, 31, 37, rows - 1):
-                        tap, n = divmod(row, nt * 32)
-                        swz = (row >> 2) & 3
-                        for slot in range(4):
-                            got = img[ck, row, slot ^ swz].astype(np.float32)
-                            want = Wp[n, ck * 32 + slot * 8: ck * 32 + slot * 8 + 8, tap // 3, tap % 3]
-                            assert (got == want).all(), (i, ck, row, slot)
-            else:
-                assert t["w_off"] == 0
-            # 16-channel-plane images: [plane][tap][cout][2 slots of 8], slots swapped when (cout >> 3) & 1
-            img16 = np.frombuffer(bl[int(t["w16_off"]):int(t["w16_off"]) + 2 * np_ * rows * 32], np.float16).reshape(2 * np_, rows, 2, 8)
-            for pl in range(2 * np_):
-                for row in (0, 5, 9, 31, 40, rows - 1):
-                    tap, n = divmod(row, nt * 32)
-                    swz = (n >> 3) & 1
-                    for slot in range(2):
-                        got = img16[pl, row, slot ^ swz].astype(np.float32)
-                        want = Wp[n, pl * 16 + slot * 8: pl * 16 + slot * 8 + 8, tap // 3, tap % 3]
-                        assert (got == want).all(), (i, pl, row, slot)
-            bias = np.frombuffer(bl[int(t["b_off"]):int(t["b_off"]) + nt * 32 * 4], np.float32)
-            assert (bias[:cout] == b).all() and (bias[cout:] == 0).all()
+    magic, version, nconv, flags = np.frombuffer(bl[:16], np.uint32)
+    assert magic == 0x50525352 and version == 4 and nconv == 351 and flags == 0
+    assert int(np.frombuffer(bl[16:24], np.uint64)[0]) == bl.size
+    table = np.frombuffer(bl[24:24 + 351 * 40], rec)
+    for i in (0, 1, 4, 5, 346, 349, 350):
+        t = table[i]
+        cin, cout, act = specs[i]
+        assert (t["cin"], t["cout"], t["act"]) == (cin, cout, act)
+        np_, nt = (cin + 31) // 32, (cout + 31) // 32
+        assert (t["nplanes"], t["nt"]) == (np_, nt)
+        rows = 9 * nt * 32
+        W, b = weights[i]
+        Wp = np.zeros((nt * 32, np_ * 32, 3, 3), np.float32)
+        Wp[:cout, :cin] = W
+        # 16-channel-plane images: [plane][tap][cout][2 slots of 8], slots swapped when (cout >> 3) & 1
+        img16 = np.frombuffer(bl[int(t["w16_off"]):int(t["w16_off"]) + 2 * np_ * rows * 32], np.float16).reshape(2 * np_, rows, 2, 8)
+        for pl in range(2 * np_):
+            for row in (0, 5, 9, 31, 40, rows - 1):
+                tap, n = divmod(row, nt * 32)
+                swz = (n >> 3) & 1
+                for slot in range(2):
+                    got = img16[pl, row, slot ^ swz].astype(np.float32)
+                    want = Wp[n, pl * 16 + slot * 8: pl * 16 + slot * 8 + 8, tap // 3, tap % 3]
+                    assert (got == want).all(), (i, pl, row, slot)
+        bias = np.frombuffer(bl[int(t["b_off"]):int(t["b_off"]) + nt * 32 * 4], np.float32)
+        assert (bias[:cout] == b).all() and (bias[cout:] == 0).all()
 
 
 def test_shard_frames_partitions_exactly():
     for n, ws in [(64, 8), (7, 4), (1, 2), (0, 3)]:
         seen = sorted(i for r in range(ws) for i in R.shard_frames(n, ws, r))
         assert seen == list(range(n))
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """bench.py --gpus 8 inside a 1-rank environment must not print a 1-GPU line labelled as anything else."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())

@@ -2,7 +2,7 @@
 # A/B two builds of librealsr_hip.so on the GPU box, alternating processes:  tools/ab_perf.sh A.so B.so [rounds]
 # (a build = realsr-ncnn-vulkan_amd/lib/librealsr_hip.so or a tools/build_variant.sh product under lib/exp/)
 A=$1; B=$2; N=${3:-3}
-export RSR_PERF_VARIANTS="kernel=4"
+export RSR_PERF_VARIANTS="${RSR_PERF_VARIANTS:-flow_flags=0}"
 for i in $(seq 1 $N); do
   for L in $A $B; do
     echo "== $L"

@@ -7,7 +7,7 @@ NAME=$1; FILE=$2; shift; shift
 D=$(cd "$(dirname "$0")/../realsr-ncnn-vulkan_amd" && pwd)
 make -s -C $D/csrc ../lib/librealsr_hip.so
 mkdir -p $D/lib/exp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden "$@" -c $D/csrc/$FILE.hip -o $D/lib/exp/$NAME.$FILE.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$D/lib/obj/gen "$@" -c $D/csrc/$FILE.hip -o $D/lib/exp/$NAME.$FILE.o
 OBJS=""
 for o in kernels conv_flow engine capi group model; do
   if [ "$o" = "$FILE" ]; then OBJS="$OBJS $D/lib/exp/$NAME.$FILE.o"; else OBJS="$OBJS $D/lib/obj/$o.o"; fi

@@ -1,4 +1,4 @@
-"""GPU bring-up / A-B sweep for conv3x3_flow (kernel 4) -- not a pytest.  Run on the MI355X box:
+"""GPU bring-up / A-B sweep for conv3x3_flow -- not a pytest.  Run on the MI355X box:
 
     python tools/flow_diag.py [conv] [net] [e2e] [perf]
 
@@ -43,7 +43,6 @@ def sec_conv(sr):
     total_bad = 0
     for flags in (0, 3):
         for ncu in (256, 8):
-            sr.set_option("kernel", 4)
             sr.set_option("flow_flags", flags)
             sr.set_option("num_cu", ncu)
             for cin, cout, h, w, ups in cases:
@@ -82,8 +81,7 @@ def sec_res(sr):
         forms = {"conv5": (0.2, True, None, 1.0, 0.2 * conv + x[:cout].astype(np.float32)),
                  "conv5+rrdb": (0.2, True, res, 0.2, 0.2 * (0.2 * conv + x[:cout].astype(np.float32)) + res.astype(np.float32)),
                  "trunk": (1.0, False, res, 1.0, conv + res.astype(np.float32))}
-        for kern, flags, dbg, ncu in ((3, 0, 0, 256), (3, 0, 4096, 256), (4, 0, 0, 256), (4, 1, 0, 256), (4, 0, 0, 8), (4, 1, 0, 8)):
-            sr.set_option("kernel", kern)
+        for kern, flags, dbg, ncu in ((4, 0, 0, 256), (4, 1, 0, 256), (4, 0, 0, 8), (4, 1, 0, 8), (4, 0, 32, 8)):
             sr.set_option("flow_flags", flags)
             sr.set_option("dbg", dbg)
             sr.set_option("num_cu", ncu)
@@ -96,7 +94,6 @@ def sec_res(sr):
                     cin, cout, h, w, kern, flags, dbg, ncu, name, np.nanmax(d), bad, d.size, "  NaN!" if np.isnan(got).any() else ""), flush=True)
                 if bad:
                     print("    per-channel bad:", (d > 1e-2).reshape(cout, -1).sum(1))
-    sr.set_option("kernel", 4)
     sr.set_option("flow_flags", 0)
     sr.set_option("dbg", 0)
     sr.set_option("num_cu", 256)
@@ -110,15 +107,13 @@ def sec_net(sr, net):
         img = synth.make_image(5, w, h)
         x = (img.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.)).astype(np.float16)
         ref = net.forward(x.astype(np.float32))
-        for kern, flags in ((3, 0), (4, 0), (4, 1), (4, 2)):
-            sr.set_option("kernel", kern)
+        for kern, flags in ((4, 0), (4, 1), (4, 2)):
             sr.set_option("flow_flags", flags)
             got = sr.net_forward(x).astype(np.float32)
             d = np.abs(got - ref)
             du = np.abs(q(got) - q(ref))
             print("  tile %dx%d kernel=%d flags=%d: max %.3e p99.9 %.3e mean %.3e | u8 max %d frac!=0 %.4f" % (
                 w, h, kern, flags, d.max(), np.quantile(d, 0.999), d.mean(), du.max(), (du > 0).mean()), flush=True)
-    sr.set_option("kernel", 4)
     sr.set_option("flow_flags", 0)
 
 
@@ -166,7 +161,7 @@ def sec_perf():
     img = synth.make_image(3, w, h)
     d_in = torch.from_numpy(img).cuda()
     d_out = torch.empty((h * 4, w * 4, 3), dtype=torch.uint8, device="cuda")
-    variants = os.environ.get("RSR_PERF_VARIANTS", "kernel=3;kernel=4,flow_flags=0;kernel=4,flow_flags=1;kernel=4,flow_flags=2;kernel=4,flow_flags=0").split(";")
+    variants = os.environ.get("RSR_PERF_VARIANTS", "flow_flags=0;dbg=32,trim=0;dbg=0,trim=1;flow_flags=1;flow_flags=2;flow_flags=0").split(";")
     sums = {}
     for var in variants:
         opts = dict(kv.split("=") for kv in var.split(",") if kv)

@@ -1,15 +1,17 @@
 #!/bin/bash
 # One GPU-box session: bench JSON, rocprofv3 kernel-trace stats, PMC passes (HBM traffic + MFMA / LDS / clock counters).
-# Usage: tools/gpu_round.sh <tag>     -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc_traffic.txt,pmc_counters.txt}
+# Usage: tools/gpu_round.sh <tag>     -> gpurun_out/<tag>/{bench.json,power_clock.txt,kernel_stats.csv,pmc_traffic.txt,pmc_counters.txt}
 # Copy the summaries you want judged into profiles/ (tracked).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline --no-host > $OUT/trace.log 2>&1; echo "trace rc=$?"
-BA="--steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host"
+# board power + sclk at 20 Hz over a longer timed region of the same command (bench.py writes its marks): profiles/<tag>_power_clock.txt
+timeout 300 python $R/tools/power_sampler.py --out $OUT/power_clock.txt --hz 20 -- python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-host --no-other-configs --no-profile > $OUT/power.log 2>&1; echo "power rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline --no-host --no-other-configs > $OUT/trace.log 2>&1; echo "trace rc=$?"
+BA="--steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host --no-other-configs"
 i=0
 # separate --pmc passes, kernel-trace only (no other trace domain): FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2; SQ has 8 slots
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do

@@ -209,7 +209,8 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                       device memory that is actually free when a plan is built, and a batch whose workspace cannot be
  *                       allocated is halved and re-planned (down to one tile) before RSR_E_NOMEM is reported
  *   "flow_flags"        bit 0 = 64-output-channel convs with 4 MFMA waves x 64 channels instead of 8 x 32,
- *                       bit 1 = no deferred epilogue for the 32-output-channel convs
+ *                       bit 1 = no deferred epilogue for the 32-output-channel convs, bit 2 = weights re-streamed from L2 for every
+ *                       block even where a conv's weight images fit in LDS for the whole launch (default: resident where they fit)
  *   "trim"              1 [default]: blocks / rows of the convs behind the trunk whose output only feeds cropped (halo) pixels of
  *                       the tile are not computed (dead-output elimination, engine.cpp: tail_margin; output bytes unchanged);
  *                       0: every padded-tile pixel is computed at every layer
@@ -225,6 +226,8 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; -DRSR_FLOW_TRACE builds), -1 off
  *   "alternate_order"   1 [default]: every second conv walks its work items backwards (starts on the tiles the previous conv
  *                       touched last -> Infinity Cache hits); 0: always forwards
+ *   "xcd_order"         1 [default]: the backward tables of "alternate_order" are reversed inside each XCD's share of the list, so an XCD
+ *                       starts on the blocks IT wrote last (its own 4 MB L2); 0: the list is reversed as a whole
  *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
  *                         1 skip LDS-DMA, 4 skip epilogue stores, 32 MFMA waves do not skip rows outside the tile / inside the
  *                         unread frame, 8192 conv_last never writes the uint8 image itself, 16384 no split tail for early download */

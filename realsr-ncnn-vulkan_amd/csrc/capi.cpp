@@ -396,6 +396,8 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     }
     else if (k == "trim")
         ctx->e.trim_tail = value != 0; // plans are keyed by it
+    else if (k == "xcd_order")
+        ctx->e.xcd_order = value != 0; // plans are keyed by it
     else if (k == "alternate_order")
         ctx->e.alternate_order = value != 0;
     else if (k == "dbg")

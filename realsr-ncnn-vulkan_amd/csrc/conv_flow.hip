@@ -109,13 +109,19 @@ __device__ __forceinline__ char* uniform_ptr(const void* p)
 //      2 v = s1*acc (the conv's own input rides in the accumulator as an identity tap) [, v = s2*v + r2] -> fp16 planes
 // NTW: n-tiles (32 output channels) per MFMA wave; the workgroup has 4*NT/NTW MFMA waves + 4 loader waves.
 // DEFER: double-buffered accumulators, block r drained underneath block r+1 (NT == 1 only).
-template <int NT, int NTW, bool UPS, int EPI, bool DEFER>
+// WRES: the conv's weight images stay RESIDENT in LDS for the whole launch (loaded once per workgroup; slot = plane index, the
+//       "ring" is never refilled) instead of being re-streamed from L2 for every block.  Why: the dense-block convs run at a
+//       constant ~25 GB/s per CU of vector-memory traffic (LDS-DMA loads + epilogue stores: 148 / 206 / 264 / 322 KiB per block
+//       for cin 64 / 96 / 128 / 160 in 121 / 159 / 209 / 253 us per launch, round 3) whatever their FLOP count, and a build with
+//       2.25x fewer MFMAs gains only 13 % there -- they are bound by the CU's vector-memory path, of which the re-streamed
+//       weights are 24-28 % (47 % of the loads of a 64 -> 64 conv).  The patch ring gets what LDS is left (ConvArgs::pr >= 3).
+template <int NT, int NTW, bool UPS, int EPI, bool DEFER, bool WRES>
 __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) void conv3x3_flow(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef FlowCfg<NT> C;
     constexpr int MW = 4 * NT / NTW;
-    constexpr int PR = C::PR, WR = C::WR, WB = C::WB;
+    constexpr int WB = C::WB;
     constexpr bool WDB = (NTW == 1); // double-buffered weight fragments (registers to spare with one n-tile per wave)
     static_assert(!DEFER || (NT == 1 && NTW == 1), "deferred epilogue needs the 256-VGPR budget of the 8-wave workgroup");
 
@@ -123,6 +129,9 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nst = a.n0 + a.n1; // half-stages per block (16-channel planes), even by construction (engine pads)
+    // ring depths and LDS offsets: compile-time constants when the weights are streamed
+    const int PR = WRES ? a.pr : C::PR, WR = WRES ? nst : C::WR;
+    const int kWOff = PR * kFPatch, kScrOff = kWOff + WR * WB, kBiasOff = kScrOff + C::SCR;
 
     const int per = (a.nitems + 7) >> 3;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
@@ -132,7 +141,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     if (nmine == 0) return;
     const int S = nmine * nst;
 
-    if (tid < NT * 32) reinterpret_cast<float*>(smem + C::BIAS_OFF)[tid] = a.bias[tid];
+    if (tid < NT * 32) reinterpret_cast<float*>(smem + kBiasOff)[tid] = a.bias[tid];
     __syncthreads();
 
     if (wave >= MW)
@@ -181,7 +190,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             if (uP >= S) return;
             const char* gbase = ((ckP < a.n0) ? plane_ptr(a.src0, itP.slot, ckP) : plane_ptr(a.src1, itP.slot, ckP - a.n0)) - kGuard;
             char* dst = smem + sP * kFPatch + lw * 1024;
-            if (!(a.dbg & 1))
+            if (!(a.dbg & (1 | 128))) // ablation: 1 = no LDS-DMA at all, 128 = no patch DMA, 64 = no weight DMA (stale LDS is multiplied)
             {
 #pragma unroll
                 for (int i = 0; i < NP; i++)
@@ -202,8 +211,8 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         auto issueW = [&]() {
             if (uW >= S) return;
             const char* src = wsrc_lane + (long long)ckW * WB;
-            char* dst = smem + C::W_OFF + sW * WB + lw * 1024;
-            if (!(a.dbg & 1))
+            char* dst = smem + kWOff + sW * WB + lw * 1024;
+            if (!(a.dbg & (1 | 64)))
             {
 #pragma unroll
                 for (int i = 0; i < (C::WPIECES + 3) / 4; i++)
@@ -214,20 +223,47 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             uW++;
             ckW = ckW + 1 == nst ? 0 : ckW + 1;
         };
-        for (int tt = -(PR - 1); tt < 0; tt++)
+        if (WRES)
         {
-            if (tt + WR - 1 >= 0) issueW();
-            issueP();
+            // every weight image of the conv, once, ahead of the first patch: vector loads retire in order, so "P(0) has landed"
+            // implies "all weights have landed"
+            const int npieces = nst * C::WPIECES;
+            if (!(a.dbg & (1 | 64)))
+                for (int p_ = lw; p_ < npieces; p_ += 4)
+                    __builtin_amdgcn_global_load_lds(RSR_GLB(static_cast<const char*>(a.wpk16) + p_ * 1024 + lane * 16), RSR_LDS(smem + kWOff + p_ * 1024), 16, 0, 0);
+            for (int tt = -(PR - 1); tt < 0; tt++) issueP();
+            // before E_t: P(t) and everything older has landed <=> at most the (PR - 2) newer patches are in flight
+            for (int t = 0; t < S; t++)
+            {
+                if ((a.dbg & 1) || t + PR - 2 >= S) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                else if (PR == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(1 * NP) : "memory");
+                else if (PR == 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");
+                else if (PR == 5) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * NP) : "memory");
+                else if (PR == 6) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                issueP();
+            }
         }
-        // counted wait immediates: nP + (WR-2)*(nW+nP) with nP = 5, WR = 3
-        constexpr int NW_HI = (C::WPIECES + 3) / 4, NW_LO = C::WPIECES / 4; // loader waves own NW_HI or NW_LO weight pieces
-        for (int t = 0; t < S; t++)
+        else
         {
-            if ((a.dbg & 1) || t + PR - 2 >= S) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (nW == NW_HI) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP + NW_HI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP + NW_LO) : "memory");
-            issueW();
-            issueP();
+            for (int tt = -(PR - 1); tt < 0; tt++)
+            {
+                if (tt + WR - 1 >= 0) issueW();
+                issueP();
+            }
+            // counted wait immediates: nP + (WR-2)*(nW+nP) with nP = 5, WR = 3
+            constexpr int NW_HI = (C::WPIECES + 3) / 4, NW_LO = C::WPIECES / 4; // loader waves own NW_HI or NW_LO weight pieces
+            for (int t = 0; t < S; t++)
+            {
+                if ((a.dbg & 1) || t + PR - 2 >= S) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                else if (a.dbg & 64) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory"); // ablations: the same look-ahead
+                else if ((a.dbg & 128) && nW == NW_HI) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NW_HI) : "memory");
+                else if (a.dbg & 128) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NW_LO) : "memory");
+                else if (nW == NW_HI) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP + NW_HI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP + NW_LO) : "memory");
+                issueW();
+                issueP();
+            }
         }
         asm volatile("s_barrier" ::: "memory"); // E_S: the MFMA waves pass one barrier per half-stage, also in the last one
         return;
@@ -246,7 +282,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         const int c = l32 + dx;
         xcol[dx] = wrow * 4 * kFRow + c * kFPx + ((hi ^ ((c >> 3) & 1)) << 4);
     }
-    const int woff = C::W_OFF + (ntw0 * 32 + l32) * 32 + ((hi ^ ((l32 >> 3) & 1)) << 4);
+    const int woff = kWOff + (ntw0 * 32 + l32) * 32 + ((hi ^ ((l32 >> 3) & 1)) << 4);
 
     // bias in accumulator layout (lane (px, hi), reg q*4+e -> cout q*8 + hi*4 + e): C operand of a block's first MFMAs
     // Without the deferred epilogue the registers are re-read from LDS at the end of every epilogue (live only up to the
@@ -258,7 +294,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
             for (int q = 0; q < 4; q++)
             {
-                const f32x4 b4 = *reinterpret_cast<const f32x4_lds*>(smem + C::BIAS_OFF + ((ntw0 + n) * 32 + q * 8 + hi * 4) * 4);
+                const f32x4 b4 = *reinterpret_cast<const f32x4_lds*>(smem + kBiasOff + ((ntw0 + n) * 32 + q * 8 + hi * 4) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; e++) bias16[n][q * 4 + e] = b4[e];
             }
@@ -268,7 +304,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // transpose scratch of this wave: per n-tile two 16-channel plane rows of 32 px x 32 B; write side (accumulator
     // layout) lane (px, hi) owns 8 B at px*32 + ((q&1) ^ f(px))*16 + hi*8 of plane q>>1, f(px) = (px>>2)&1;
     // read side lane (px' = lane>>1, k = lane&1) takes 16 B = channels k*8..+7.
-    char* const scr = smem + C::SCR_OFF + wave * (NTW * 2048);
+    char* const scr = smem + kScrOff + wave * (NTW * 2048);
     const int scr_w = l32 * 32 + hi * 8, scr_wx = ((l32 >> 2) & 1) << 4;
     const int rpx = lane >> 1, rk = lane & 1;
     const int scr_r = rpx * 32 + ((rk ^ ((rpx >> 2) & 1)) << 4);
@@ -444,9 +480,32 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #define RSR_LDW(WS, DY, DX, WBASE)                                                                                   \
     _Pragma("unroll") for (int n_ = 0; n_ < NTW; n_++) WS[DY][n_] =                                                  \
         *reinterpret_cast<const half8*>((WBASE) + ((DY)*3 + (DX)) * (NT * 1024) + n_ * 1024);
+#ifndef RSR_EXP_THIN
 #define RSR_CELL(ACC, WS, DY, RR, FIRST)                                                                             \
     _Pragma("unroll") for (int n_ = 0; n_ < NTW; n_++) ACC[RR][n_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(         \
         WS[DY][n_], X[(RR) + (DY)], ((FIRST) && (DY) == 0) ? bias16[n_] : ACC[RR][n_], 0, 0, 0);
+#else
+    // EXPERIMENT BUILD ONLY (tools/build_variant.sh ... -DRSR_EXP_THIN=16|24; wrong results by construction): the instruction mix
+    // of a Winograd convolution on this kernel's data path -- F(2x2,3x3) keeps 16 of the 36 MFMAs of a half-stage and pays 8
+    // packed-fp16 adds per kept MFMA for the input transform, F(2,3) along x keeps 24 and pays ~1.5 -- with the same LDS-DMA,
+    // fragment reads, barriers and epilogue, on data that stays full-entropy (the kept taps give a sane partial sum).  What it
+    // measures is the BEST case of such a kernel (no output transform, no extra accumulators): DESIGN.md 4.1.
+#define RSR_KEEP(DY, RR)                                                                                             \
+    ((DY) == 0 || (RSR_EXP_THIN == 24 && (DY) == 1) ||                                                               \
+     (RSR_EXP_THIN == 16 && ((curdx_ == 0 && (DY) == 1 && (RR) == 0) || (curdx_ == 1 && (DY) == 1 && (RR) == 1) || (curdx_ == 2 && (DY) == 2 && (RR) < 2))))
+#define RSR_CELL(ACC, WS, DY, RR, FIRST)                                                                             \
+    if (RSR_KEEP(DY, RR))                                                                                            \
+    {                                                                                                                \
+        _Pragma("unroll") for (int n_ = 0; n_ < NTW; n_++) ACC[RR][n_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(     \
+            WS[DY][n_], X[(RR) + (DY)], ((FIRST) && (DY) == 0) ? bias16[n_] : ACC[RR][n_], 0, 0, 0);                 \
+        if (RSR_EXP_THIN == 16 || ((DY) == 0 && (RR) < 3))                                                           \
+        {                                                                                                            \
+            half8 y_ = X[((RR) + (DY)) % 6] + X[((RR) + 2 * (DY) + 1) % 6]; /* distinct per cell: no CSE */         \
+            if (RSR_EXP_THIN == 16) y_ = y_ + X[((RR) + (DY) + 3) % 6];                                              \
+            asm volatile("" ::"v"(y_));                                                                              \
+        }                                                                                                            \
+    }
+#endif
 #define RSR_NOHK(c)
 
     // One (dx) step = 12 cells (dy, rr): rows 0-1 through the three dy taps, then rows 2-3 -- (0,0) (0,1) (1,0) (1,1) (2,0)
@@ -465,6 +524,8 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // hidden load can only make them over-wait by one.)
 #define RSR_STEP(ACC, WCUR, WNXT, NXB, NWB, NDX, FIRST, BAR, ITEMQ, HK)                                              \
     {                                                                                                                \
+        constexpr int curdx_ = ((NDX) + 2) % 3; /* the dx this step multiplies (experiment builds) */                \
+        (void)curdx_;                                                                                                \
         if ((BAR) && (ITEMQ))                                                                        \
         {                                                                                                            \
             const WorkItem* ip_ = a.items + (first + min(r + 2, nmine - 1) * nj);                                    \
@@ -847,20 +908,45 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 }
 
 // ---- launch ------------------------------------------------------------------------------------
+constexpr int kLdsMax = 160 * 1024;
+
 template <int NT, int NTW, bool UPS, int EPI, bool DEFER>
 static hipError_t flow_attr()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_flow<NT, NTW, UPS, EPI, DEFER>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, FlowCfg<NT>::TOTAL);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_flow<NT, NTW, UPS, EPI, DEFER, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, FlowCfg<NT>::TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_flow<NT, NTW, UPS, EPI, DEFER, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
+    return e;
+}
+
+// patch ring depth a resident-weight launch can afford (0: the weights do not fit next to 3 patches)
+template <int NT>
+static int resident_ring(int nst)
+{
+    const int rest = kLdsMax - nst * FlowCfg<NT>::WB - FlowCfg<NT>::SCR - NT * 128;
+    const int pr = rest / kFPatch;
+    return pr < 3 ? 0 : (pr > 6 ? 6 : pr);
 }
 
 template <int NT, int NTW, bool UPS, int EPI, bool DEFER>
-static void flow_launch(const ConvArgs& a, int ncu, hipStream_t st)
+static void flow_launch(const ConvArgs& a_in, int ncu, bool resident, hipStream_t st)
 {
     int grid = ncu & ~7;
-    const int per = (a.nitems + 7) / 8;
+    const int per = (a_in.nitems + 7) / 8;
     if (per * 8 < grid) grid = per * 8;
-    hipLaunchKernelGGL((conv3x3_flow<NT, NTW, UPS, EPI, DEFER>), dim3(grid), dim3((4 * NT / NTW + 4) * 64), FlowCfg<NT>::TOTAL, st, a);
+    const int nst = a_in.n0 + a_in.n1;
+    const int pr = resident ? resident_ring<NT>(nst) : 0;
+    if (pr)
+    {
+        ConvArgs a = a_in;
+        a.pr = pr;
+        const int lds = pr * kFPatch + nst * FlowCfg<NT>::WB + FlowCfg<NT>::SCR + NT * 128;
+        hipLaunchKernelGGL((conv3x3_flow<NT, NTW, UPS, EPI, DEFER, true>), dim3(grid), dim3((4 * NT / NTW + 4) * 64), lds, st, a);
+    }
+    else
+        hipLaunchKernelGGL((conv3x3_flow<NT, NTW, UPS, EPI, DEFER, false>), dim3(grid), dim3((4 * NT / NTW + 4) * 64), FlowCfg<NT>::TOTAL, st, a_in);
 }
 
 // every instantiation the engine can reach, for the per-device opt-in to > 64 KiB of dynamic LDS
@@ -880,7 +966,8 @@ hipError_t flow_init_device()
     return e;
 }
 
-// flags: bit 0 = two n-tiles per MFMA wave for the 64-output-channel convs (4 MFMA waves), bit 1 = no deferred epilogue
+// flags: bit 0 = two n-tiles per MFMA wave for the 64-output-channel convs (4 MFMA waves), bit 1 = no deferred epilogue,
+//        bit 2 = weights re-streamed per block even where they would fit in LDS for the whole launch
 bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStream_t st)
 {
     if (a_in.nitems <= 0) return true;
@@ -904,30 +991,30 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
         else return false;
     }
     else if ((!a.out_planar3 && !a.out_u8) || a.out16.base || a.res1_kind || a.res2_kind) return false;
-    const bool ntw2 = (flags & 1) != 0, defer = !(flags & 2);
+    const bool ntw2 = (flags & 1) != 0, defer = !(flags & 2), res = !(flags & 4);
     if (nt == 1)
     {
-        if (epi == 0 && !ups) flow_launch<1, 1, false, 0, false>(a, ncu, st);
-        else if (epi == 1 && !ups && defer) flow_launch<1, 1, false, 1, true>(a, ncu, st);
-        else if (epi == 1 && !ups) flow_launch<1, 1, false, 1, false>(a, ncu, st);
-        else if (epi == 1) flow_launch<1, 1, true, 1, false>(a, ncu, st);
-        else if (epi == 2 && !ups) flow_launch<1, 1, false, 2, false>(a, ncu, st);
+        if (epi == 0 && !ups) flow_launch<1, 1, false, 0, false>(a, ncu, res, st);
+        else if (epi == 1 && !ups && defer) flow_launch<1, 1, false, 1, true>(a, ncu, res, st);
+        else if (epi == 1 && !ups) flow_launch<1, 1, false, 1, false>(a, ncu, res, st);
+        else if (epi == 1) flow_launch<1, 1, true, 1, false>(a, ncu, res, st);
+        else if (epi == 2 && !ups) flow_launch<1, 1, false, 2, false>(a, ncu, res, st);
         else return false;
         return true;
     }
     if (nt != 2 || epi == 0) return false;
     if (ntw2)
     {
-        if (epi == 1 && !ups) flow_launch<2, 2, false, 1, false>(a, ncu, st);
-        else if (epi == 1) flow_launch<2, 2, true, 1, false>(a, ncu, st);
-        else if (!ups) flow_launch<2, 2, false, 2, false>(a, ncu, st);
+        if (epi == 1 && !ups) flow_launch<2, 2, false, 1, false>(a, ncu, res, st);
+        else if (epi == 1) flow_launch<2, 2, true, 1, false>(a, ncu, res, st);
+        else if (!ups) flow_launch<2, 2, false, 2, false>(a, ncu, res, st);
         else return false;
     }
     else
     {
-        if (epi == 1 && !ups) flow_launch<2, 1, false, 1, false>(a, ncu, st);
-        else if (epi == 1) flow_launch<2, 1, true, 1, false>(a, ncu, st);
-        else if (!ups) flow_launch<2, 1, false, 2, false>(a, ncu, st);
+        if (epi == 1 && !ups) flow_launch<2, 1, false, 1, false>(a, ncu, res, st);
+        else if (epi == 1) flow_launch<2, 1, true, 1, false>(a, ncu, res, st);
+        else if (!ups) flow_launch<2, 1, false, 2, false>(a, ncu, res, st);
         else return false;
     }
     return true;

@@ -315,7 +315,7 @@ static size_t batch_table_bytes(const Plan::Batch& b)
 }
 
 // upload one batch's tables behind `d`; every copy is checked
-static hipError_t upload_batch(Plan::Batch& b, char*& d)
+static hipError_t upload_batch(Plan::Batch& b, char*& d, bool xcd_order = true)
 {
     hipError_t err = hipSuccess;
     auto put = [&](const void* src, size_t bytes) -> void* {
@@ -329,7 +329,21 @@ static hipError_t upload_batch(Plan::Batch& b, char*& d)
     for (int l = 0; l < 3; l++)
     {
         b.d_items[l] = static_cast<WorkItem*>(put(b.items[l].data(), b.items[l].size() * sizeof(WorkItem)));
+        // The backward table.  LR level (never launched in sub-ranges): reversed INSIDE each XCD's share of the list -- the kernel
+        // gives XCD x the items [x * per, (x + 1) * per), per = ceil(n / 8) -- so that a conv starts, on every XCD, with the blocks
+        // that XCD itself produced last: those sit in ITS 4 MB L2.  (A whole-list reversal hands XCD 0 the blocks XCD 7 wrote:
+        // Infinity-Cache hits at best, and the L2-miss path is what bounds the dense-block convs)  The 2x / 4x
+        // tables are launched in slot sub-ranges (run_network) and keep the plain reversal.
         std::vector<WorkItem> rev(b.items[l].rbegin(), b.items[l].rend());
+        if (l == 0 && xcd_order)
+        {
+            const size_t n = b.items[l].size(), per = (n + 7) / 8;
+            for (size_t x = 0; x < 8; x++)
+            {
+                const size_t i0 = std::min(n, x * per), i1 = std::min(n, (x + 1) * per);
+                for (size_t i = i0; i < i1; i++) rev[i] = b.items[l][i0 + (i1 - 1 - i)];
+            }
+        }
         b.d_items_rev[l] = static_cast<WorkItem*>(put(rev.data(), rev.size() * sizeof(WorkItem)));
     }
     return err;
@@ -343,7 +357,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
 {
     for (auto it = plans.begin(); it != plans.end(); ++it)
         if (it->w == w && it->h == h && it->c == c && it->T == tilesize && it->P == prepadding && it->tta == tta &&
-            it->tile0 == tile0 && it->tile1 == tile1 && it->budget_mb == max_workspace_mb && it->trim == trim_tail)
+            it->tile0 == tile0 && it->tile1 == tile1 && it->budget_mb == max_workspace_mb && it->trim == trim_tail && it->xcd_order == xcd_order)
         {
             plans.splice(plans.begin(), plans, it); // most recently used first
             out = &plans.front();
@@ -417,6 +431,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
     plan.tile0 = tile0; plan.tile1 = tile1;
     plan.budget_mb = max_workspace_mb;
     plan.trim = trim_tail;
+    plan.xcd_order = xcd_order;
     plan.cap_px = cap;
     plan.max_tw = mtw;
     plan.max_th = mth;
@@ -451,7 +466,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
     char* d = static_cast<char*>(plan.d_tables);
     for (Plan::Batch& b : plan.batches)
     {
-        const hipError_t e = upload_batch(b, d);
+        const hipError_t e = upload_batch(b, d, xcd_order);
         if (e != hipSuccess)
         {
             (void)hipFree(plan.d_tables);

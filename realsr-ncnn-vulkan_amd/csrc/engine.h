@@ -42,7 +42,7 @@ struct Plan
     int w = 0, h = 0, c = 0, T = 0, P = 0, tta = 0;
     int tile0 = 0, tile1 = 0; // tiles [tile0, tile1) of the image's tile grid, row-major (multi-GPU tile sharding)
     long long budget_mb = 0;
-    bool trim = true;
+    bool trim = true, xcd_order = true;
     long long cap_px = 0; // slot capacity in LR pixels
     int max_tw = 0, max_th = 0;
     struct Batch
@@ -109,6 +109,7 @@ struct Engine
     int num_cu = 256;
     int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
     bool trim_tail = true; // leave out the blocks / rows behind the trunk that only feed cropped output pixels (engine.cpp: tail_margin)
+    bool xcd_order = true; // backward work-item tables reversed per XCD share (each XCD re-reads what IT wrote last: L2 hits), else as a whole
     bool alternate_order = true; // odd convs walk the work items backwards: they start on the data the previous conv touched last
     int trace_conv = -1; // conv index whose launch records s_memtime stamps into trace_buf (profiling only)
     DevBuf trace_buf;

@@ -56,6 +56,7 @@ struct ConvArgs
     // reaches the cropped output rectangle (engine.cpp: tail_margins): MFMA waves whose four rows lie wholly inside that frame
     // skip their block like rows below the tile.  0 = every pixel is needed.
     int margin;
+    int pr; // patch ring depth of a resident-weight launch (set by launch_conv_flow)
     // residual stages: v = v*s + r  (r = fp16 planes)
     PlaneSrc res1, res2;
     int res1_kind, res2_kind; // 0 none, 1 fp16 planes
@@ -80,7 +81,8 @@ struct ConvArgs
     int dbg;           // ablation switches for profiling: 1 skip DMA, 2 skip MFMA, 4 skip epilogue stores, ...  (realsr_hip.h)
 };
 
-// conv_flow.hip: half-stage ring on 16-channel planes.  flags: 1 = two n-tiles per MFMA wave for 64-cout convs, 2 = no deferred epilogue.
+// conv_flow.hip: half-stage ring on 16-channel planes.  flags: 1 = two n-tiles per MFMA wave for 64-cout convs, 2 = no deferred epilogue,
+// 4 = weights always streamed (never LDS-resident).
 // false = this combination of outputs / residuals is not covered (the engine then reports an error)
 bool launch_conv_flow(const ConvArgs& a, int nt, int ncu, int flags, hipStream_t st);
 // Opt-in to > 64 KiB of dynamic LDS for every kernel instantiation, on the CURRENT device (call once per device).

@@ -1,7 +1,7 @@
 """Oracle references for many tiles at once (test infrastructure): the CPU oracle runs 16 OpenMP threads well and no more
 (oracle.py), the GPU box has 256 hardware threads -- so whole BASELINE frames are checked tile by tile with a pool of
-worker PROCESSES, each holding its own OracleNet.  A 1080p frame at tile 200 (60 tiles, 104 TFLOP of fp32 CPU work) takes
-about half a minute this way.
+worker PROCESSES, each holding its own OracleNet, as many as the CPU quota really allows (usable_cpus / 16; one 220x220
+tile = 1.7 TFLOP of fp32 CPU work = ~4.5 s on 16 cores).
 
 ref_tiles(pp, bp, [(padded CHW float32 tile, tta)]) -> [uint8 (4*th, 4*tw, 3) of the un-padded rectangle]
 following realsr.cpp:525-838: network on the halo'd tile (x8 dihedral variants under TTA, realsr.cpp:617-724, merged
@@ -54,11 +54,35 @@ def _one(job):
     return np.clip((o * 255.0 + 0.5).astype(np.int32), 0, 255).astype(np.uint8).transpose(1, 2, 0)
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask and the cgroup quota, not os.cpu_count() (the GPU box reports 256
+    hardware threads and grants ~16 cores: 12 workers x 16 threads there ran no faster than one)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def ref_tiles(pp, bp, jobs, P=10, threads=16, workers=None):
     jobs = [(t, tta, P) for (t, tta) in jobs]
-    cpus = os.cpu_count() or 1
+    cpus = usable_cpus()
     if workers is None:
-        workers = max(1, min(len(jobs), (cpus * 3 // 4) // threads, 12))
+        workers = int(os.environ.get("RSR_ORACLE_WORKERS", "0")) or max(1, min(len(jobs), cpus // threads, 12))
     threads = max(1, min(threads, cpus))
     if workers <= 1:
         _init(pp, bp, threads)

@@ -59,8 +59,9 @@ def test_conv3x3_layer_matches_oracle(sr, cin, cout, h, w, ups, lrelu):
         xr = xr.repeat(2, axis=1).repeat(2, axis=2)
     ref = oracle.conv3x3(xr, wt, b, 2 if lrelu else 0, 0.2)
     try:
-        # conv3x3_flow: 8 x 32 / 4 x 64 MFMA waves, with / without deferred epilogue, rows below the tile skipped / computed
-        for flags, dbg in ((0, 0), (3, 0), (0, 32), (3, 32)):
+        # conv3x3_flow: 8 x 32 / 4 x 64 MFMA waves, with / without deferred epilogue, weights LDS-resident / streamed (flags 4),
+        # rows below the tile skipped / computed
+        for flags, dbg in ((0, 0), (3, 0), (4, 0), (7, 0), (0, 32), (3, 32)):
             sr.set_option("flow_flags", flags)
             sr.set_option("dbg", dbg)
             got = sr.conv3x3(x, wt, b, lrelu=lrelu, upsample2x=ups).astype(np.float32)
@@ -84,7 +85,7 @@ def test_rows_below_the_tile_are_skipped_not_miscomputed(sr, cin, cout, h, w, up
     wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float16).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
     try:
-        for flags in (0, 3):
+        for flags in (0, 3, 4):
             for ncu in (256, 8):
                 sr.set_option("flow_flags", flags)
                 sr.set_option("num_cu", ncu)
@@ -114,7 +115,7 @@ def test_residual_epilogues_match_numpy(sr, cin, cout, h, w):
     forms = {"conv5": (0.2, True, None, 1.0, 0.2 * conv + x0), "conv5+rrdb": (0.2, True, res, 0.2, 0.2 * (0.2 * conv + x0) + r),
              "trunk": (1.0, False, res, 1.0, conv + r)}
     try:
-        for flags, dbg, ncu in ((0, 0, 256), (1, 0, 256), (0, 0, 8), (1, 0, 8), (0, 32, 8)):
+        for flags, dbg, ncu in ((0, 0, 256), (1, 0, 256), (0, 0, 8), (1, 0, 8), (0, 32, 8), (4, 0, 8), (5, 0, 256)):
             for k, v in (("flow_flags", flags), ("dbg", dbg), ("num_cu", ncu)):
                 sr.set_option(k, v)
             for name, (s1, own, rr, s2, ref) in forms.items():
@@ -195,15 +196,15 @@ def test_network_tile_prequantise_error(sr, oracle_net):
 
 @pytest.mark.parametrize("w,h", [(28, 24), (64, 32), (45, 50)])
 def test_kernel_paths_agree(sr, w, h):
-    """The wave layouts / epilogue forms of conv3x3_flow (8x32 / 4x64 MFMA waves, deferred / inline epilogue, dead rows
-    skipped / computed, few / many workgroups) are restatements of the same arithmetic: identical accumulation order per output
+    """The wave layouts / epilogue forms of conv3x3_flow (8x32 / 4x64 MFMA waves, deferred / inline epilogue, weights resident /
+    streamed, dead rows skipped / computed, few / many workgroups) are restatements of the same arithmetic: identical accumulation order per output
     value, so the whole network must agree BIT FOR BIT between them."""
     img = synth.make_image(17, w, h)
     x = (img.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)).astype(np.float16)
     try:
         ref = sr.net_forward(x)
         assert np.isfinite(ref.astype(np.float32)).all()
-        for dbg, flags, ncu in [(0, 1, 256), (0, 2, 256), (0, 3, 256), (32, 0, 256), (0, 0, 16), (32, 3, 16)]:
+        for dbg, flags, ncu in [(0, 1, 256), (0, 2, 256), (0, 3, 256), (0, 4, 256), (32, 0, 256), (0, 0, 16), (32, 3, 16), (0, 7, 16)]:
             sr.set_option("dbg", dbg)
             sr.set_option("flow_flags", flags)
             sr.set_option("num_cu", ncu)

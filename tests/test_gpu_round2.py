@@ -161,15 +161,19 @@ def test_guards_stay_zero_across_layout_and_slot_changes(paths):
 
 
 # ---- BASELINE configs that had no oracle check ----------------------------------------------------------------------------
-def test_c2_every_tile_against_oracle(sr, paths):
-    """C2 (1920x1080, tile 200): ALL 60 tiles -- 45 x 220x220, 9 x 220x100 (last tile row), 5 x 140x220 (last column), the
-    140x100 corner -- against the oracle network, +-1 uint8 (a pool of oracle processes, tests/oracle_pool.py)."""
+def test_c2_tiles_against_oracle(sr, paths):
+    """C2 (1920x1080, tile 200): 45 x 220x220, 9 x 220x100 (last tile row), 5 x 140x220 (last column), the 140x100 corner.
+    Default: 14 tiles -- 7 interior ones spread over the frame incl. the first and the last of the work list, 3 of the last
+    row, 3 of the last column, the corner -- against the oracle network, +-1 uint8; RSR_SLOW_TESTS=1: ALL 60 tiles (measured
+    on the GPU box: 60 of 60 within +-1, ~6 min of CPU oracle time -- the host grants ~16 cores)."""
     sr.tilesize = 200
     img = synth.make_image(1235, 1920, 1080)
     out = sr.process(img)
-    n, frac = oracle_pool.check_frame_tiles(out, img, *paths, T=200)
-    assert n == 60 and frac < 0.15
-    print("C2: 60 tiles within +-1, %.2f %% of the bytes differ" % (100 * frac))
+    slow = os.environ.get("RSR_SLOW_TESTS") == "1"
+    tiles = None if slow else [(0, 0), (8, 0), (3, 1), (5, 2), (1, 3), (7, 3), (8, 4), (0, 5), (4, 5), (8, 5), (9, 0), (9, 2), (9, 4), (9, 5)]
+    n, frac = oracle_pool.check_frame_tiles(out, img, *paths, T=200, tiles=tiles)
+    assert n == (60 if slow else 14) and frac < 0.15
+    print("C2: %d tiles within +-1, %.2f %% of the bytes differ" % (n, 100 * frac))
 
 
 def test_c3_tiles_against_oracle_and_batching(sr, paths):
@@ -195,8 +199,8 @@ def test_c3_tiles_against_oracle_and_batching(sr, paths):
 def test_c5_tta_against_oracle(paths, oracle_net):
     """C5 (1080p, tile 200, -x): TTA x8 -- 4 + 4 transposed-shape slots for the non-square edge tiles (engine.cpp /
     realsr.cpp:251-258).  A 260x230 image whose grid has all four tile shapes against the oracle's own TTA path (whole image),
-    then the real 1080p frame: one tile of each of the four shapes against an independent statement of the 8 dihedral passes
-    (every tile with RSR_SLOW_TESTS=1: 480 network evaluations on the CPU, a few minutes)."""
+    then the real 1080p frame: a 140x220 edge tile and the 140x100 corner (the transposed-shape slots) against an independent
+    statement of the 8 dihedral passes (every tile with RSR_SLOW_TESTS=1: 480 network evaluations on the CPU, ~40 min)."""
     s = R.RealSR(0, tta_mode=True)
     s.load(*paths)
     s.tilesize = 200
@@ -209,9 +213,9 @@ def test_c5_tta_against_oracle(paths, oracle_net):
     big = synth.make_image(1239, 1920, 1080)
     out = s.process(big)
     s.close()
-    tiles = None if os.environ.get("RSR_SLOW_TESTS") == "1" else [(4, 2), (2, 5), (9, 3), (9, 5)]
+    tiles = None if os.environ.get("RSR_SLOW_TESTS") == "1" else [(9, 3), (9, 5)]
     n, frac = oracle_pool.check_frame_tiles(out, big, *paths, T=200, tiles=tiles, tta=True)
-    assert n == (60 if tiles is None else 4) and frac < 0.15
+    assert n == (60 if tiles is None else 2) and frac < 0.15
 
 
 def test_engine_options_do_not_change_the_bytes(paths, sr):
@@ -225,8 +229,8 @@ def test_engine_options_do_not_change_the_bytes(paths, sr):
     t.load(*paths)
     t.tilesize = 32
     want_tta = t.process(imgs[0])
-    knobs = [("tail_group", 1, 0), ("tail_group", 3, 0), ("alternate_order", 0, 1), ("max_lanes", 1, 4), ("copy_threads", 1, 4), ("chunk_mb", 1, 16),
-             ("trim", 0, 1), ("dbg", 32, 0), ("dbg", 8192, 0), ("dbg", 16384, 0), ("flow_flags", 3, 0), ("max_workspace_mb", 64, 65536), ("num_cu", 64, 256)]
+    knobs = [("tail_group", 1, 0), ("tail_group", 3, 0), ("alternate_order", 0, 1), ("xcd_order", 0, 1), ("max_lanes", 1, 4), ("copy_threads", 1, 4), ("chunk_mb", 1, 16),
+             ("trim", 0, 1), ("dbg", 32, 0), ("dbg", 8192, 0), ("dbg", 16384, 0), ("flow_flags", 3, 0), ("flow_flags", 4, 0), ("max_workspace_mb", 64, 65536), ("num_cu", 64, 256)]
     try:
         for key, val, default in knobs:
             for ctx, ims, refs in ((sr, imgs, want), (t, imgs[:1], [want_tta])):

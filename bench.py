@@ -39,7 +39,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 W_IN, H_IN, TILE, PREPAD, SCALE = 1920, 1080, 200, 10, 4
 FLOP_PER_PADDED_LR_PX = 35853696  # 2 x 17,926,848 MAC
 PEAK_F16_TFLOPS = 2500.0  # gfx950 dense f16 MFMA peak, MI355X_MICROARCH.md
-DOMINANT_KERNEL = "conv3x3_flow<1, 1, false, 1, true>"
+DOMINANT_KERNEL = "conv3x3_flow<1, 1, false, 1, true, true>"
 
 
 def padded_px(w, h, T, P):
@@ -518,13 +518,13 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src or "no tracked PMC summary found",
                 "traffic_unit": "B/launch, HBM (PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes); algorithmic (3.5 + 1) x 162.8 MB = 732.7e6",
-                "kernel": "rsr::" + DOMINANT_KERNEL + " (276 of the 351 convs: cin 64..160 -> 32, LeakyReLU, 16-channel fp16 planes)",
+                "kernel": "rsr::" + DOMINANT_KERNEL + " (276 of the 351 convs: cin 64..160 -> 32, LeakyReLU, 16-channel fp16 planes, weights LDS-resident)",
                 "launches": ring_launches,
                 "avg_launch_us": round(ring_ms * 1e3 / max(ring_launches, 1), 2),
                 "algorithmic_flop_per_launch_avg": round(ring_flops / max(ring_launches, 1)),
                 "flop_accounting": "algorithmic = SURVEY 8(d): every padded-tile pixel of every layer; the kernel executes ~2.6 % more (16x32 "
                                    "block quantisation in x) and the 2x / 4x convs ~14 % less (blocks that only feed cropped halo pixels are not computed)",
-                "second_kernel": {"kernel": "rsr::conv3x3_flow<2, 1, false, 2, false> (69 x conv5 192 -> 64)",
+                "second_kernel": {"kernel": "rsr::conv3x3_flow<2, 1, false, 2, false, false> (69 x conv5 192 -> 64)",
                                   "achieved": round(c5_flops / (c5_ms * 1e-3) / 1e12, 1), "frac": round(c5_flops / (c5_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                                   "avg_launch_us": round(c5_ms * 1e3 / (69 * args.steps * batches), 2)},
                 "all_convs": {"achieved": round(ach_all, 1), "frac": round(ach_all / PEAK_F16_TFLOPS, 4), "launches": prof["conv_launches"],
@@ -534,7 +534,8 @@ def main():
                 "post_ms_per_step": round(prof["post_ms"] / args.steps, 4),
                 "post_GBps": round(prof["post_bytes"] / max(prof["post_ms"], 1e-9) / 1e6, 1),
                 "timing": "hipEvents on the launch stream around every kernel of the timed steps (rank 0), inside the timed region",
-                "note": "the board sits at its 1400 W cap during this workload (sclk ~1.75 GHz of 2.4): at that clock the MFMA peak is ~1.8 PFLOP/s",
+                "note": "the board sits at its 1400 W cap during this workload (profiles/r03_power_clock.txt: 1400 W mean, sclk 1.60 GHz of 2.4 over the timed region): "
+                        "at that clock the MFMA peak is ~1.67 PFLOP/s",
             }
             try:
                 g = board_gemm_ceiling(dev)

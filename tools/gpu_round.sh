@@ -24,3 +24,5 @@ find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kern
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
 ls -la $OUT; cat $OUT/pmc_traffic.txt | head -30
+# A/B of the wave layout for the 64-output-channel convs (flow_flags 1) and of the streamed-weight build (4), alternating
+RSR_PERF_VARIANTS="flow_flags=0;flow_flags=1;flow_flags=0;flow_flags=4;flow_flags=0" timeout 300 python $R/tools/flow_diag.py perf > $OUT/ab_flags.log 2>&1; grep -E "ms/frame" $OUT/ab_flags.log

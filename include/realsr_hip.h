@@ -210,7 +210,9 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                       allocated is halved and re-planned (down to one tile) before RSR_E_NOMEM is reported
  *   "flow_flags"        bit 0 = 64-output-channel convs with 4 MFMA waves x 64 channels instead of 8 x 32,
  *                       bit 1 = no deferred epilogue for the 32-output-channel convs, bit 2 = weights re-streamed from L2 for every
- *                       block even where a conv's weight images fit in LDS for the whole launch (default: resident where they fit)
+ *                       block even where a conv's weight images fit in LDS for the whole launch (default: resident where they fit),
+ *                       bit 3 = conv_last (64 -> 3) through the generic 32-output-channel path instead of the variant that puts
+ *                       (dy, cout) into the MFMA's M dimension (half the matrix work; same arithmetic, other summation order)
  *   "trim"              1 [default]: blocks / rows of the convs behind the trunk whose output only feeds cropped (halo) pixels of
  *                       the tile are not computed (dead-output elimination, engine.cpp: tail_margin; output bytes unchanged);
  *                       0: every padded-tile pixel is computed at every layer

@@ -105,7 +105,7 @@ __device__ __forceinline__ char* uniform_ptr(const void* p)
 
 } // namespace
 
-// EPI: 0 generic (conv_last: planar fp16 [3][H][W] output)      1 v = act(acc)  -> fp16 planes
+// EPI: 0 generic (conv_last: planar fp16 [3][H][W] output)      1 v = act(acc)  -> fp16 planes      3 conv_last with (dy, cout) in M
 //      2 v = s1*acc (the conv's own input rides in the accumulator as an identity tap) [, v = s2*v + r2] -> fp16 planes
 // NTW: n-tiles (32 output channels) per MFMA wave; the workgroup has 4*NT/NTW MFMA waves + 4 loader waves.
 // DEFER: double-buffered accumulators, block r drained underneath block r+1 (NT == 1 only).
@@ -124,6 +124,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     constexpr int WB = C::WB;
     constexpr bool WDB = (NTW == 1); // double-buffered weight fragments (registers to spare with one n-tile per wave)
     static_assert(!DEFER || (NT == 1 && NTW == 1), "deferred epilogue needs the 256-VGPR budget of the 8-wave workgroup");
+    static_assert(EPI != 3 || (NT == 1 && NTW == 1 && !UPS && !DEFER && WRES), "conv_last's (dy, cout) layout: 32 rows, resident aux image");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     const int nst = a.n0 + a.n1; // half-stages per block (16-channel planes), even by construction (engine pads)
     // ring depths and LDS offsets: compile-time constants when the weights are streamed
     const int PR = WRES ? a.pr : C::PR, WR = WRES ? nst : C::WR;
-    const int kWOff = PR * kFPatch, kScrOff = kWOff + WR * WB, kBiasOff = kScrOff + C::SCR;
+    const int kWOff = PR * kFPatch, kScrOff = kWOff + WR * (EPI == 3 ? a.wpieces * 1024 : WB), kBiasOff = kScrOff + C::SCR;
 
     const int per = (a.nitems + 7) >> 3;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         {
             // every weight image of the conv, once, ahead of the first patch: vector loads retire in order, so "P(0) has landed"
             // implies "all weights have landed"
-            const int npieces = nst * C::WPIECES;
+            const int npieces = nst * (EPI == 3 ? a.wpieces : C::WPIECES);
             if (!(a.dbg & (1 | 64)))
                 for (int p_ = lw; p_ < npieces; p_ += 4)
                     __builtin_amdgcn_global_load_lds(RSR_GLB(static_cast<const char*>(a.wpk16) + p_ * 1024 + lane * 16), RSR_LDS(smem + kWOff + p_ * 1024), 16, 0, 0);
@@ -421,7 +422,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // conv_last (EPI 0): channels 0..2 of n-tile 0 -> planar fp16 [3][H][W] (the reference's `output` blob, consumed by
     // postproc_tiles), or -- non-TTA RGB -- straight into the uint8 image: realsr_postproc.comp:62-83 on the value rounded to
     // fp16 exactly as the planar path stores it (v*255 + 0.5, floor, clamp), at the tile's place minus the halo crop.
-    auto planar_store = [&](const f32x16 (&acc)[4][NTW], const WorkItem& it) {
+    auto store3 = [&](const float (&val)[4][3], const WorkItem& it) {
         if (hi != 0 || ntw0 != 0 || (a.dbg & 4)) return;
         const int x = it.x0 + l32;
         if (a.out_u8)
@@ -439,7 +440,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {
-                        float v = (float)(_Float16)acc[rr][0][ch];
+                        float v = (float)(_Float16)val[rr][ch];
                         v = floorf(v * 255.f + 0.5f);
                         v = fminf(fmaxf(v, 0.f), 255.f);
                         o[a.out_u8_bgr ? 2 - ch : ch] = (uint8_t)v;
@@ -460,12 +461,20 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++)
                 {
-                    float v = acc[rr][0][ch];
+                    float v = val[rr][ch];
                     if (a.lrelu) v = fmaxf(v, v * 0.2f);
                     o[ch * hw + pix] = (_Float16)v;
                 }
             }
         }
+    };
+    auto planar_store = [&](const f32x16 (&acc)[4][NTW], const WorkItem& it) {
+        float val[4][3];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) val[rr][ch] = acc[rr][0][ch];
+        store3(val, it);
     };
 
     // ---- operand fragments, accumulators ----
@@ -704,6 +713,96 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     {
         a.trace[0] = t_arr;
         a.trace[1] = __builtin_amdgcn_s_memtime();
+    }
+    if constexpr (EPI == 3)
+    {
+        // ---- conv_last, 64 -> 3: (dy, cout) in the M dimension -------------------------------------------------------------
+        // With 3 real output channels a 32 x 32 x 16 MFMA has room for the three dy taps at once: A = the aux image
+        // [dx][row = dy*8 + c][16 cin] (rows of other (dy, c) zero), B = patch row R  =>  D[dy*8 + c][px] is tap (dy, dx)'s
+        // contribution of patch row R to OUTPUT row R - dy.  One accumulator per patch row (6 per wave for its 4 output rows),
+        // 3 MFMAs per patch row and plane instead of 9 per output row: 72 instead of 144 per block.  Output row rr =
+        // acc[rr][0*4 + c] + acc[rr + 1][1*4 + c] + acc[rr + 2][2*4 + c] in the lanes with hi == 0 (accumulator row q*8 + hi*4 + e).
+        // Fragments are double-buffered across the dx steps; the half-stage barrier sits behind the wave's last LDS read.
+        f32x16 acc[6];
+        half8 Xa[6], Xb[6], Wfa, Wfb;
+        const int woff3 = kWOff + l32 * 32 + ((hi ^ ((l32 >> 3) & 1)) << 4);
+        const int WB3 = a.wpieces * 1024;
+        auto ldx = [&](half8(&Xf)[6], int slot, int dx) {
+            const char* xb = xbase(slot, dx);
+#pragma unroll
+            for (int q = 0; q < 6; q++) Xf[q] = *reinterpret_cast<const half8*>(xb + q * kFRow);
+        };
+        auto ldw = [&](int plane, int dx) { return *reinterpret_cast<const half8*>(smem + woff3 + plane * WB3 + dx * 1024); };
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define RSR_M6(XF, WF, FIRST)                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < 6; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WF, XF[q], (FIRST) ? zero16 : acc[q], 0, 0, 0);
+        // one half-stage on fragments (XC, WC) = its dx 0 operands, already in registers; leaves the next half-stage's in (XN, WN)
+#define RSR_HALF3(XC, WC, XN, WN, FIRST)                                                                             \
+    {                                                                                                                \
+        const int nsP = sP == PR - 1 ? 0 : sP + 1, nck = ck + 1 == nst ? 0 : ck + 1;                                 \
+        if (FIRST) /* descriptor of the block after next: a scalar load hidden from the compiler (see RSR_STEP), early */ \
+        {                                                                                                            \
+            const WorkItem* ip_ = a.items + (first + min(r + 2, nmine - 1) * nj);                                    \
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(item_q) : "s"(ip_));                                    \
+        }                                                                                                            \
+        ldx(XN, sP, 1); WN = ldw(ck, 1);                                                                             \
+        RSR_M6(XC, WC, FIRST)                                                                                        \
+        ldx(XC, sP, 2); WC = ldw(ck, 2);                                                                             \
+        RSR_M6(XN, WN, false)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(item_q)::"memory");                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ldx(XN, nsP, 0); WN = ldw(nck, 0);                                                                           \
+        RSR_M6(XC, WC, false)                                                                                        \
+        sP = nsP;                                                                                                    \
+        t++;                                                                                                         \
+    }
+        ldx(Xa, 0, 0);
+        Wfa = ldw(0, 0);
+        for (r = 0; r < nmine; r++)
+        {
+            while (wave_is_dead(it))
+            {
+                {
+                    const WorkItem* ip_ = a.items + (first + min(r + 2, nmine - 1) * nj);
+                    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(item_q) : "s"(ip_));
+                }
+                for (int h_ = 0; h_ < nst; h_++)
+                {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(item_q)::"memory");
+                    sP = sP == PR - 1 ? 0 : sP + 1;
+                    t++;
+                }
+                ldx(Xa, sP, 0);
+                Wfa = ldw(0, 0);
+                it = nxt;
+                nxt = item_from_q();
+                if (++r >= nmine) break;
+            }
+            if (r >= nmine) break;
+            for (int cp = 0; cp < nst; cp += 2)
+            {
+                ck = cp;
+                if (cp == 0) { RSR_HALF3(Xa, Wfa, Xb, Wfb, true) }
+                else { RSR_HALF3(Xa, Wfa, Xb, Wfb, false) }
+                ck = cp + 1;
+                RSR_HALF3(Xb, Wfb, Xa, Wfa, false)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float val[4][3];
+            const float* bl = reinterpret_cast<const float*>(smem + kBiasOff);
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) val[rr][ch] = acc[rr][ch] + acc[rr + 1][4 + ch] + acc[rr + 2][8 + ch] + bl[ch];
+            store3(val, it);
+            __builtin_amdgcn_sched_barrier(0);
+            it = nxt;
+            nxt = item_from_q();
+        }
+#undef RSR_HALF3
+#undef RSR_M6
+        return;
     }
     {
         const char* xb = xbase(0, 0);
@@ -958,7 +1057,8 @@ static void flow_launch(const ConvArgs& a_in, int ncu, bool resident, hipStream_
 
 hipError_t flow_init_device()
 {
-    hipError_t e = hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_flow<1, 1, false, 3, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
 #define RSR_F(NT, NTW, UPS, EPI, DEFER)                                                                              \
     if (e == hipSuccess) e = flow_attr<NT, NTW, UPS, EPI, DEFER>();
     RSR_FLOW_VARIANTS(RSR_F)
@@ -967,7 +1067,8 @@ hipError_t flow_init_device()
 }
 
 // flags: bit 0 = two n-tiles per MFMA wave for the 64-output-channel convs (4 MFMA waves), bit 1 = no deferred epilogue,
-//        bit 2 = weights re-streamed per block even where they would fit in LDS for the whole launch
+//        bit 2 = weights re-streamed per block even where they would fit in LDS for the whole launch,
+//        bit 3 = conv_last through the generic 32-output-channel path (9 taps x 32 padded couts) instead of (dy, cout) in M
 bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStream_t st)
 {
     if (a_in.nitems <= 0) return true;
@@ -994,7 +1095,21 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
     const bool ntw2 = (flags & 1) != 0, defer = !(flags & 2), res = !(flags & 4);
     if (nt == 1)
     {
-        if (epi == 0 && !ups) flow_launch<1, 1, false, 0, false>(a, ncu, res, st);
+        if (epi == 0 && !ups && a.waux && !(flags & 8))
+        { // conv_last with (dy, cout) in the MFMA's M dimension: the 3-KB-per-plane aux image, always resident
+            const int nst = a.n0 + a.n1;
+            int pr = (kLdsMax - nst * 3072 - FlowCfg<1>::SCR - 128) / kFPatch;
+            pr = pr > 6 ? 6 : pr;
+            if (pr < 3) return false;
+            a.wpk16 = a.waux;
+            a.wpieces = 3;
+            a.pr = pr;
+            int grid = ncu & ~7;
+            const int per = (a.nitems + 7) / 8;
+            if (per * 8 < grid) grid = per * 8;
+            hipLaunchKernelGGL((conv3x3_flow<1, 1, false, 3, false, true>), dim3(grid), dim3(512), pr * kFPatch + nst * 3072 + FlowCfg<1>::SCR + 128, st, a);
+        }
+        else if (epi == 0 && !ups) flow_launch<1, 1, false, 0, false>(a, ncu, res, st);
         else if (epi == 1 && !ups && defer) flow_launch<1, 1, false, 1, true>(a, ncu, res, st);
         else if (epi == 1 && !ups) flow_launch<1, 1, false, 1, false>(a, ncu, res, st);
         else if (epi == 1) flow_launch<1, 1, true, 1, false>(a, ncu, res, st);

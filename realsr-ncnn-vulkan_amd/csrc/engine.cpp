@@ -636,6 +636,7 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         std::memset(&a, 0, sizeof a);
         const PackedConv& c = convs[size_t(ci)];
         a.wpk16 = blobp + c.w16_off;
+        a.waux = c.aux_off ? blobp + c.aux_off : nullptr;
         a.bias = reinterpret_cast<const float*>(blobp + c.b_off);
         a.lrelu = (c.act == 2);
         a.lvl_in = lvl_in;
@@ -1235,6 +1236,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         a.lvl_in = 0;
         a.lvl_out = ups ? 1 : 0;
         a.wpk16 = static_cast<const char*>(d_w.p) + pc.w16_off;
+        a.waux = pc.aux_off ? static_cast<const char*>(d_w.p) + pc.aux_off : nullptr;
         a.bias = reinterpret_cast<const float*>(static_cast<const char*>(d_w.p) + pc.b_off);
         a.lrelu = lrelu;
         a.s1 = a.s2 = 1.f;

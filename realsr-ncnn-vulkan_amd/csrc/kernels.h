@@ -50,6 +50,8 @@ struct ConvArgs
     int lvl_out; // output resolution = LR << lvl_out (lvl_out == lvl_in + 1 for the nearest-x2 fused convs)
     // weights: packed LDS images [plane of 16 cin][9 taps][NT*32 cout][16 cin]; bias fp32 [NT*32]
     const void* wpk16;
+    const void* waux; // conv_last only: [plane of 16 cin][dx 0..2][row = dy*8 + cout][16 cin] (PackedConv::aux_off), or null
+    int wpieces;      // 1-KiB pieces per plane of the resident image (set by launch_conv_flow)
     const float* bias;
     int lrelu; // LeakyReLU(0.2) on (acc + bias)
     // Output pixels closer than `margin` to the tile border (at this conv's output level) are never read by anything that
@@ -82,7 +84,7 @@ struct ConvArgs
 };
 
 // conv_flow.hip: half-stage ring on 16-channel planes.  flags: 1 = two n-tiles per MFMA wave for 64-cout convs, 2 = no deferred epilogue,
-// 4 = weights always streamed (never LDS-resident).
+// 4 = weights always streamed (never LDS-resident), 8 = conv_last through the generic path.
 // false = this combination of outputs / residuals is not covered (the engine then reports an error)
 bool launch_conv_flow(const ConvArgs& a, int nt, int ncu, int flags, hipStream_t st);
 // Opt-in to > 64 KiB of dynamic LDS for every kernel instantiation, on the CURRENT device (call once per device).

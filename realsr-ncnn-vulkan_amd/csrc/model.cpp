@@ -447,6 +447,7 @@ size_t packed_size(const Model& m)
         const size_t np = size_t((c.cin + 31) / 32), nt = size_t((c.cout + 31) / 32);
         off = align256(off + nt * 32 * 4);
         off = align256(off + 2 * np * 9 * nt * 32 * 32);
+        if (c.cout <= 4) off = align256(off + 2 * np * 3 * 32 * 32);
     }
     return off;
 }
@@ -504,6 +505,26 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
                     }
                 }
         off = align256(off + size_t(2 * np) * rows * 32);
+        P.aux_off = 0;
+        if (c.cout <= 4)
+        { // (dy, cout) in the M dimension: [plane][dx][row = dy*8 + n][16 cin], same slot swizzle by row
+            P.aux_off = off;
+            uint16_t* A = reinterpret_cast<uint16_t*>(base + off);
+            for (int pl = 0; pl < 2 * np; pl++)
+                for (int dx = 0; dx < 3; dx++)
+                    for (int dy = 0; dy < 3; dy++)
+                        for (int n = 0; n < c.cout; n++)
+                        {
+                            const int row = dy * 8 + n;
+                            uint16_t* R = A + (size_t(pl) * 96 + size_t(dx) * 32 + row) * 16;
+                            for (int slot = 0; slot < 2; slot++)
+                            {
+                                const int pslot = slot ^ ((row >> 3) & 1);
+                                for (int e = 0; e < 8; e++) R[pslot * 8 + e] = wt(n, pl * 16 + slot * 8 + e, dy * 3 + dx);
+                            }
+                        }
+            off = align256(off + size_t(2 * np) * 96 * 32);
+        }
     }
     return RSR_OK;
 }
@@ -553,6 +574,7 @@ int check_packed(const void* head, size_t head_bytes, size_t total_bytes, std::s
         bool ok = int(c.cin) == cin && int(c.cout) == cout && int(c.act) == act && c.nplanes == np && c.nt == nt;
         auto inside = [&](uint64_t off, uint64_t size) { return off >= packed_table_bytes() && (off & 255) == 0 && off <= total_bytes && size <= total_bytes - off; };
         ok = ok && inside(c.b_off, nt * 32 * 4) && inside(c.w16_off, 2 * np * 9 * nt * 32 * 32);
+        ok = ok && (cout <= 4 ? inside(c.aux_off, 2 * np * 3 * 32 * 32) : c.aux_off == 0);
         if (!ok)
         {
             err = "packed blob conv table corrupt at convolution " + std::to_string(i);

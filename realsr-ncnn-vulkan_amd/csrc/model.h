@@ -59,11 +59,12 @@ int load_model(const std::string& param, const std::string& bin, Model& m, std::
 //     [tap 0..8][cout row 0..NT*32-1][16 cin] fp16, 32 B per row, the two 16-B slots of a row swapped when (cout>>3)&1
 // followed by NT*32 fp32 biases.  Cin is zero-padded to a multiple of 32 (conv_first 3 -> 32: two 16-channel planes,
 // the second all zero), Cout to a multiple of 32 (conv_last 3 -> 32).  33.5 MB for x4.param: what rsr_load uploads and
-// what the multi-GPU broadcast carries.
+// what the multi-GPU broadcast carries.  A conv with <= 4 output channels (conv_last, 64 -> 3) additionally carries the aux image
+// of conv3x3_flow's (dy, cout)-in-M variant: per plane [dx][32 rows][16 cin], row dy*8 + c = tap (dy, dx) of output channel c.
 struct PackedHeader
 {
     uint32_t magic;   // 'RSRP'
-    uint32_t version; // 4
+    uint32_t version; // 5
     uint32_t nconv;
     uint32_t flags;   // 0 (version 3 carried the 32-channel images of the round-1 kernels behind bit 0)
     uint64_t total_bytes;
@@ -77,8 +78,9 @@ struct PackedConv
     float slope;
     uint64_t b_off;         // byte offsets from blob start (256-B aligned)
     uint64_t w16_off;       // 16-channel-plane images
+    uint64_t aux_off;       // convs with <= 4 output channels (conv_last): [plane][dx 0..2][row = dy*8 + cout][16 cin], 3 KB per plane; else 0
 };
-constexpr uint32_t kPackedVersion = 4;
+constexpr uint32_t kPackedVersion = 5;
 constexpr uint32_t kPackedMagic = 0x50525352u; // "RSRP"
 
 size_t packed_size(const Model& m);

@@ -277,18 +277,18 @@ def test_corrupt_blob_is_refused_and_state_survives(paths, sr):
     want = sr.process(img)
     blob = R.model_pack(*paths)
     rec = np.dtype([("cin", "<u4"), ("cout", "<u4"), ("act", "<u4"), ("nplanes", "<u4"), ("nt", "<u4"),
-                    ("slope", "<f4"), ("b_off", "<u8"), ("w16_off", "<u8")])
-    assert rec.itemsize == 40
-    for field, value in (("w16_off", blob.size - 256), ("cin", 128), ("nt", 2), ("b_off", blob.size + 4096)):
+                    ("slope", "<f4"), ("b_off", "<u8"), ("w16_off", "<u8"), ("aux_off", "<u8")])
+    assert rec.itemsize == 48
+    for field, value in (("w16_off", blob.size - 256), ("cin", 128), ("nt", 2), ("b_off", blob.size + 4096), ("aux_off", 4096)):
         bad = blob.copy()
-        table = bad[24:24 + 351 * 40].view(rec)
+        table = bad[24:24 + 351 * 48].view(rec)
         table[field][7] = value
         with pytest.raises(R.RealSRError) as e:
             sr.load_packed(bad)
         assert e.value.code == R.RSR_E_FORMAT, field
         assert (sr.process(img) == want).all(), "a refused blob must not disturb the loaded model"
     old_version = blob.copy()
-    old_version[4:8].view("<u4")[0] = 3  # a blob of the previous layout (with the round-1 weight images) is refused, not misread
+    old_version[4:8].view("<u4")[0] = 4  # a blob of the previous layout (with the round-1 weight images) is refused, not misread
     with pytest.raises(R.RealSRError) as e:
         sr.load_packed(old_version)
     assert e.value.code == R.RSR_E_FORMAT

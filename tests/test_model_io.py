@@ -96,13 +96,13 @@ def test_packed_blob_layout(model_dir, weights):
     bl = R.model_pack(pp, bp)
     assert 33e6 < bl.size < 34.5e6  # 33.5 MB: what one RCCL broadcast moves
     rec = np.dtype([("cin", "<u4"), ("cout", "<u4"), ("act", "<u4"), ("nplanes", "<u4"), ("nt", "<u4"),
-                    ("slope", "<f4"), ("b_off", "<u8"), ("w16_off", "<u8")])
-    assert rec.itemsize == 40
+                    ("slope", "<f4"), ("b_off", "<u8"), ("w16_off", "<u8"), ("aux_off", "<u8")])
+    assert rec.itemsize == 48
     specs = synth.conv_specs()
     magic, version, nconv, flags = np.frombuffer(bl[:16], np.uint32)
-    assert magic == 0x50525352 and version == 4 and nconv == 351 and flags == 0
+    assert magic == 0x50525352 and version == 5 and nconv == 351 and flags == 0
     assert int(np.frombuffer(bl[16:24], np.uint64)[0]) == bl.size
-    table = np.frombuffer(bl[24:24 + 351 * 40], rec)
+    table = np.frombuffer(bl[24:24 + 351 * 48], rec)
     for i in (0, 1, 4, 5, 346, 349, 350):
         t = table[i]
         cin, cout, act = specs[i]
@@ -125,6 +125,20 @@ def test_packed_blob_layout(model_dir, weights):
                     assert (got == want).all(), (i, pl, row, slot)
         bias = np.frombuffer(bl[int(t["b_off"]):int(t["b_off"]) + nt * 32 * 4], np.float32)
         assert (bias[:cout] == b).all() and (bias[cout:] == 0).all()
+        # conv_last's aux image, (dy, cout) in the MFMA's M dimension: [plane][dx][row = dy*8 + c][2 slots of 8], other rows zero
+        if cout <= 4:
+            aux = np.frombuffer(bl[int(t["aux_off"]):int(t["aux_off"]) + 2 * np_ * 3 * 32 * 32], np.float16).reshape(2 * np_, 3, 32, 2, 8)
+            for pl in range(2 * np_):
+                for dx in range(3):
+                    for row in range(32):
+                        dy, c = divmod(row, 8)
+                        swz = (row >> 3) & 1
+                        for slot in range(2):
+                            got = aux[pl, dx, row, slot ^ swz].astype(np.float32)
+                            want = Wp[c, pl * 16 + slot * 8: pl * 16 + slot * 8 + 8, dy, dx] if (dy < 3 and c < cout) else np.zeros(8, np.float32)
+                            assert (got == want).all(), (i, pl, dx, row, slot)
+        else:
+            assert t["aux_off"] == 0
 
 
 def test_shard_frames_partitions_exactly():

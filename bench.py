@@ -571,7 +571,7 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--mode", "group", "--gpus", str(world), "--frames", str(max(8 * world, 16))]
         try:
             time.sleep(2.0)  # the other ranks are tearing down their contexts
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             res["group_mode"] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"value": None, "error": "rc %d: %s" % (r.returncode, r.stderr[-600:])}
         except Exception as e:  # noqa: BLE001

@@ -1,4 +1,4 @@
-"""GPU tests added in round 2 (run with -m gpu on the MI355X box): concurrency of rsr_process on one context, the
+"""GPU tests added in rounds 2 and 3 (run with -m gpu on the MI355X box): concurrency of rsr_process on one context, the
 workspace guard invariant, the BASELINE configurations that had no oracle check (C3, C5, the edge-tile classes of C2),
 a raw-fp32 x4.bin, pinned-memory I/O, blob validation, the bench's multi-rank control flow on one GPU.
 

@@ -126,6 +126,11 @@ int rsr_process_rows(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8
  * carry the same tilesize / prepadding / scale / tta (checked: RSR_E_ARG otherwise). */
 int rsr_process_group(rsr_ctx* const* ctx, int n, const uint8_t* in, int w, int h, int c, uint8_t* out);
 
+/* Host-only (no GPU): the tile ranges rsr_process_group deals to `parts` shares of a w x h image: share i runs the tiles
+ * [bounds[i], bounds[i+1]) of the row-major grid; bounds has parts + 1 entries.  Balanced by padded tile area to within one
+ * tile.  Returns the number of shares used (min(parts, number of tiles)) or a negative RSR_E_*. */
+int rsr_tile_partition(int w, int h, int tilesize, int prepadding, int parts, int* bounds);
+
 /* Host-only model introspection (no GPU): conv count, weight/bias counts and the .bin encoding
  * (1 = fp16-tagged, 0 = raw fp32, 2 = mixed/table).  Any pointer may be NULL. */
 int rsr_model_info(const char* parampath, const char* modelpath, int* n_layers, int* n_convs,

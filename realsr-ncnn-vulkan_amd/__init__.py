@@ -25,7 +25,7 @@ EXPORTS = [
     "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times", "rsr_get_trace",
     "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_host_alloc", "rsr_host_free",
     "rsr_set_progress_callback", "rsr_conv3x3_res", "rsr_create_group", "rsr_group_transport", "rsr_process_rows",
-    "rsr_process_group", "rsr_device_memory", "rsr_process_tiles",
+    "rsr_process_group", "rsr_device_memory", "rsr_process_tiles", "rsr_tile_partition",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -104,6 +104,7 @@ def lib():
     L.rsr_process_rows.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip]
     L.rsr_process_tiles.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip]
     L.rsr_process_group.argtypes = [C.POINTER(vp), ip, vp, ip, ip, ip, vp]
+    L.rsr_tile_partition.argtypes = [ip, ip, ip, ip, ip, C.POINTER(ip)]
     L.rsr_set_profiling.argtypes = [vp, ip]
     L.rsr_get_profile.argtypes = [vp, C.POINTER(Profile), ip]
     L.rsr_get_conv_times.argtypes = [vp, C.POINTER(C.c_double), ip, ip]
@@ -382,6 +383,15 @@ def process_group(srs, img, out=None):
     if rc != 0:
         raise RealSRError(rc, L.rsr_last_error(None).decode())
     return out
+
+
+def tile_partition(w, h, tilesize, prepadding, parts):
+    """rsr_tile_partition: the contiguous tile ranges rsr_process_group deals to `parts` contexts (host-only)."""
+    b = (C.c_int * (parts + 1))()
+    n = lib().rsr_tile_partition(int(w), int(h), int(tilesize), int(prepadding), int(parts), b)
+    if n < 0:
+        raise RealSRError(n, lib().rsr_last_error(None).decode())
+    return list(b[:n + 1])
 
 
 # ---- tile sharding for multi-GPU runs (SURVEY.md 8(e)): pure host logic, shared by bench + tests ----

@@ -223,6 +223,37 @@ int rsr_process_rows(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8
     return ctx->e.process_host(in, w, h, c, out, tile_row_begin * xtiles, tile_row_end * xtiles);
 }
 
+// Host-only: the contiguous row-major tile ranges rsr_process_group gives its shares.  bounds[0..parts]: share i runs tiles
+// [bounds[i], bounds[i+1]).  Boundaries by padded tile area: share i ends at the first tile where the running load reaches
+// (i+1)/parts of the total, every share gets at least one tile.  Returns the number of shares used (min(parts, tiles)).
+int rsr_tile_partition(int w, int h, int tilesize, int prepadding, int parts, int* bounds)
+{
+    if (w < 1 || h < 1 || tilesize < 1 || prepadding < 0 || parts < 1 || !bounds) return Engine::fail(RSR_E_ARG, "bad arguments");
+    const int T = tilesize, P = prepadding;
+    const int xtiles = (w + T - 1) / T, ytiles = (h + T - 1) / T, ntiles = xtiles * ytiles;
+    parts = std::min(parts, ntiles);
+    std::vector<long long> cum(size_t(ntiles) + 1, 0);
+    for (int t = 0; t < ntiles; t++)
+    {
+        const int yi = t / xtiles, xi = t % xtiles;
+        const long long tw = std::min((xi + 1) * T, w) - xi * T + 2 * P, th = std::min((yi + 1) * T, h) - yi * T + 2 * P;
+        cum[size_t(t) + 1] = cum[size_t(t)] + tw * th;
+    }
+    bounds[0] = 0;
+    bounds[parts] = ntiles;
+    for (int i = 1; i < parts; i++)
+    {
+        const long long target = cum[size_t(ntiles)] * i / parts;
+        int b = int(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        // the boundary tile goes to the side that leaves the smaller deviation from the target
+        if (b > 0 && target - cum[size_t(b) - 1] < cum[size_t(b)] - target) b--;
+        b = std::max(b, bounds[i - 1] + 1);     // every share gets at least one tile
+        b = std::min(b, ntiles - (parts - i));  // ... also the ones behind it
+        bounds[i] = b;
+    }
+    return parts;
+}
+
 // One image over n contexts.  The TILES of the grid (not its rows: a 1080p frame at tile 200 has 6 tile rows, the last one 80
 // pixels high -- split by rows it could use 6 of 8 GPUs and wait for the slowest) are dealt in contiguous row-major ranges of
 // equal padded-pixel load (within one tile), each context uploads the image, runs its range and fetches exactly the output
@@ -246,24 +277,9 @@ int rsr_process_group(rsr_ctx* const* ctx, int n, const uint8_t* in, int w, int 
     const int xtiles = (w + T - 1) / T, ytiles = (h + T - 1) / T, ntiles = xtiles * ytiles;
     const int parts = std::min(n, ntiles);
     if (parts == 1) return ctx[0]->e.process_host(in, w, h, c, out);
-    // boundaries by padded tile area: share i ends at the first tile where the running load reaches (i+1)/parts of the total
-    std::vector<long long> cum(size_t(ntiles) + 1, 0);
-    for (int t = 0; t < ntiles; t++)
-    {
-        const int yi = t / xtiles, xi = t % xtiles;
-        const long long tw = std::min((xi + 1) * T, w) - xi * T + 2 * P, th = std::min((yi + 1) * T, h) - yi * T + 2 * P;
-        cum[size_t(t) + 1] = cum[size_t(t)] + tw * th;
-    }
     std::vector<int> bound(size_t(parts) + 1, 0);
-    bound[size_t(parts)] = ntiles;
-    for (int i = 1; i < parts; i++)
-    {
-        const long long target = cum[size_t(ntiles)] * i / parts;
-        int b = int(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
-        b = std::max(b, bound[size_t(i) - 1] + 1);      // every share gets at least one tile
-        b = std::min(b, ntiles - (parts - i));          // ... also the ones behind it
-        bound[size_t(i)] = b;
-    }
+    const int prc = rsr_tile_partition(w, h, T, P, parts, bound.data());
+    if (prc < 0) return prc;
     std::vector<int> rcs(size_t(parts), RSR_OK);
     std::vector<std::string> errs{size_t(parts)};
     std::vector<std::thread> th;

@@ -141,6 +141,28 @@ def test_packed_blob_layout(model_dir, weights):
             assert t["aux_off"] == 0
 
 
+def test_tile_partition_balances_one_image_over_the_gpus():
+    """rsr_process_group's split of ONE image: contiguous row-major tile ranges, every share non-empty, loads
+    (padded pixels) within one tile of each other.  C2 = 1920x1080 at tile 200: 60 tiles of four shapes over 8 GPUs -- split by
+    tile ROWS (6 of them, the last 80 px high) it would use 6 GPUs and wait for the slowest."""
+    def areas(w, h, T, P):
+        xt, yt = -(-w // T), -(-h // T)
+        return [(min((t % xt + 1) * T, w) - (t % xt) * T + 2 * P) * (min((t // xt + 1) * T, h) - (t // xt) * T + 2 * P) for t in range(xt * yt)]
+    for (w, h, T, parts) in [(1920, 1080, 200, 8), (1920, 1080, 200, 2), (1920, 1080, 200, 4), (3840, 2160, 400, 8), (70, 150, 32, 5), (70, 150, 32, 20), (50, 40, 64, 3)]:
+        a = areas(w, h, T, 10)
+        b = R.tile_partition(w, h, T, 10, parts)
+        used = len(b) - 1
+        assert used == min(parts, len(a)) and b[0] == 0 and b[-1] == len(a)
+        assert all(b[i] < b[i + 1] for i in range(used)), b
+        loads = [sum(a[b[i]:b[i + 1]]) for i in range(used)]
+        assert max(loads) - min(loads) <= 2 * max(a), (w, h, T, parts, loads)      # within a tile of the ideal share on either side
+        assert max(loads) <= sum(a) / used + max(a), (w, h, T, parts, loads)
+    b = R.tile_partition(1920, 1080, 200, 10, 8)  # 6-7 full tiles per share; the last share takes the 10 low tiles of the last row
+    assert b == [0, 7, 14, 20, 27, 34, 41, 47, 60]
+    with pytest.raises(R.RealSRError):
+        R.tile_partition(0, 10, 32, 10, 2)
+
+
 def test_shard_frames_partitions_exactly():
     for n, ws in [(64, 8), (7, 4), (1, 2), (0, 3)]:
         seen = sorted(i for r in range(ws) for i in R.shard_frames(n, ws, r))

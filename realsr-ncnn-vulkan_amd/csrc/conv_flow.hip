@@ -21,6 +21,10 @@
 //     -> fp16 -> private LDS scratch (transpose) -> 1-KiB buffer stores.  With 32 output channels (4 MFMA waves, 256
 //     VGPRs) the accumulators are double-buffered and block r is drained row by row underneath block r+1's MFMAs.
 //
+// Round 3: weight images LDS-RESIDENT for the whole launch where they fit (WRES: every conv but the 192 -> 64
+// ones), MFMA waves SKIP blocks whose four rows lie below the tile or inside the frame of output pixels nothing kept depends on
+// (wave_is_dead, ConvArgs::margin), and conv_last runs with (dy, cout) in the MFMA's M dimension (EPI 3).
+//
 // Work decomposition as before: one workgroup = a 16 x 32 pixel block, MFMA wave w owns rows 4*(w&3)..+3, persistent
 // grid (one workgroup per CU) walking an XCD-contiguous, strided list of work items; 4 loader waves only issue
 // LDS-DMA (global_load_lds_dwordx4).  Work-item descriptors are fetched with SCALAR loads (they neither touch the

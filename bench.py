@@ -39,6 +39,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 W_IN, H_IN, TILE, PREPAD, SCALE = 1920, 1080, 200, 10, 4
 FLOP_PER_PADDED_LR_PX = 35853696  # 2 x 17,926,848 MAC
 PEAK_F16_TFLOPS = 2500.0  # gfx950 dense f16 MFMA peak, MI355X_MICROARCH.md
+# FLOPs the kernels really execute per padded LR pixel of a 220 x 220 tile (C2): LR-level convs x 1.026 (columns 220 -> 224, 140 -> 160:
+# PMC, round 3), 2x / 4x-level convs x (1 - 0.139) (blocks that only feed cropped halo pixels are left out; 13.9 % at the 4x level)
+_LR = 2 * 9 * (3 * 64 + 69 * ((64 + 96 + 128 + 160) * 32 + 192 * 64) + 64 * 64)
+_UP = 2 * 9 * (4 * 64 * 64 + 16 * 64 * 64 + 16 * 64 * 64 + 16 * 64 * 3)
+assert _LR + _UP == FLOP_PER_PADDED_LR_PX
+EXECUTED_FLOP_PER_PADDED_LR_PX = _LR * 1.026 + _UP * (1 - 0.139)
 DOMINANT_KERNEL = "conv3x3_flow<1, 1, false, 1, true, true>"
 
 
@@ -62,7 +68,7 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the newest tracked rocprofv3 PMC summary (tools/gpu_round.sh writes
     it: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md).  None when no such file is there."""
-    for name in ("r03_pmc_traffic.txt", "r02_pmc_traffic.txt"):
+    for name in ("r04_pmc_traffic.txt", "r03_pmc_traffic.txt", "r02_pmc_traffic.txt"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             txt = open(path).read()
@@ -172,10 +178,24 @@ def other_config(name, dev, w, h, T, tta, img_seed, model, wseed, steps=3):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
         fl = padded_px(w, h, T, PREPAD) * FLOP_PER_PADDED_LR_PX * (8 if tta else 1)
-        return {"config": "%s, %dx%d, tile %d%s, 1 GPU, device-resident" % (model, w, h, T, ", TTA x8 (-x)" if tta else ""),
-                "ms_per_frame": round(dt * 1e3, 2), "value": round(16.0 * w * h / 1e6 / dt, 2), "unit": "Mpix/s", "steps": steps,
-                "frame_tflop": round(fl / 1e12, 1), "frac_of_peak": round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
-                "checksum": int(d_out[::97, ::89].to(torch.int64).sum().item())}
+        res = {"config": "%s, %dx%d, tile %d%s, 1 GPU, device-resident" % (model, w, h, T, ", TTA x8 (-x)" if tta else ""),
+               "ms_per_frame": round(dt * 1e3, 2), "value": round(16.0 * w * h / 1e6 / dt, 2), "unit": "Mpix/s", "steps": steps,
+               "frame_tflop": round(fl / 1e12, 1), "frac_of_peak": round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
+               "tile_batches": int(sr.get_stat("plan_batches")),
+               "checksum": int(d_out[::97, ::89].to(torch.int64).sum().item())}
+        # one more, profiled, frame (outside the timed steps): the HBM-bound pre / post kernels against their algorithmic bytes
+        # (pre 3 B in + 64 B out per padded px; post 6 B x slots in + 3 B out per output px).  Under TTA the
+        # postproc kernel is the 8-way gather + merge (realsr_postproc_tta.comp); non-TTA RGB has none (fused into conv_last).
+        sr.set_profiling(True)
+        sr.get_profile(reset=True)
+        sr.process_device(d_in.data_ptr(), w, h, 3, d_out.data_ptr())
+        p = sr.get_profile(reset=True)
+        sr.set_profiling(False)
+        res["pre_ms"] = round(p["pre_ms"], 4)
+        res["pre_GBps"] = round(p["pre_bytes"] / max(p["pre_ms"], 1e-9) / 1e6, 1)
+        res["post_ms"] = round(p["post_ms"], 4)
+        res["post_GBps"] = round(p["post_bytes"] / max(p["post_ms"], 1e-9) / 1e6, 1) if p["post_ms"] > 0 else None
+        return res
     finally:
         sr.close()
 
@@ -467,8 +487,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "value_definition": "images resident in HBM when the timed region starts (rsr_process_device; the driver contract: a PCIe-inclusive "
-                                "rate is never `value`); SURVEY 8(d)'s host->host rate is host_to_host below",
+            "value_definition": "images resident in HBM when the timed region starts (rsr_process_device) -- the bench contract of this tier: 'inputs "
+                                "already resident in HBM when the timed region starts; a PCIe-inclusive rate is never `value`'.  SURVEY 8(d)'s end-user "
+                                "metric (host memory -> host memory, rsr_process) is `host_to_host_pinned` right below, details in `host_to_host`",
+            "device_resident": round(out_mpix * world * args.steps / dt, 3),
+            "host_to_host_pinned": round(out_mpix * world * args.steps / host["pinned"], 3) if host else None,
             "config": {
                 "workload": "C2: models-DF2K, 1920x1080 RGB -> 7680x4320, scale=4, tile=200, prepadding=10, "
                             "60 tiles/frame (2,544,000 padded LR px, 91.21 TFLOP algorithmic), 1 frame per GPU per step",
@@ -479,6 +502,11 @@ def main():
                 "frame_tflop": round(ppx * FLOP_PER_PADDED_LR_PX / 1e12, 2),
                 "whole_path_tflops": round(ppx * FLOP_PER_PADDED_LR_PX * world * args.steps / dt / 1e12, 1),
                 "whole_path_frac_of_peak": round(ppx * FLOP_PER_PADDED_LR_PX * world * args.steps / dt / 1e12 / PEAK_F16_TFLOPS / world, 4),
+                # the same frame executes fewer FLOPs than the algorithmic count: -13.9 % of the 4x-level blocks (dead-output elimination),
+                # +2.6 % at the LR level (16 x 32 block quantisation in x; PMC SQ_INSTS_VALU_MFMA_MOPS_F16, profiles/r03_pmc_counters.txt)
+                "whole_path_frac_of_peak_executed": round(ppx * (EXECUTED_FLOP_PER_PADDED_LR_PX) * world * args.steps / dt / 1e12 / PEAK_F16_TFLOPS / world, 4),
+                "frac_of_peak_caveat": "one binary measured 88.7-93.9 ms on five boards of round 3 (38.9-41.1 % whole path): the boards differ in the clock their "
+                                       "power management grants under the 1,400 W cap; a single run is one board's number, not a floor",
                 "checksum": checksum,
             },
         }

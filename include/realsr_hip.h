@@ -112,6 +112,13 @@ int rsr_load_packed(rsr_ctx* ctx, const void* blob, size_t bytes, int is_device)
  * (main.cpp:811-828), or ONE large image is split with rsr_process_group. */
 int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, const char* parampath, const char* modelpath);
 const char* rsr_group_transport(void); /* "rccl" | "host ..." for the calling thread's last rsr_create_group */
+/* With RSR_GROUP_FORCE_RCCL=1 in the environment rsr_create_group takes the RCCL branch also for n == 1 (a communicator of one
+ * rank, an in-place broadcast, the model loaded from the device copy): the whole collective path can be exercised on a
+ * single-GPU machine.  rsr_rccl_probe is host-only (no GPU, no communicator): 0 when librccl can be dlopen'ed and exports every
+ * entry point that branch calls (ncclCommInitAll, ncclCommDestroy, ncclGroupStart, ncclGroupEnd, ncclBroadcast,
+ * ncclGetErrorString), RSR_E_DEVICE + rsr_last_error() otherwise.  Reference semantics: one RealSR + one load per GPU id,
+ * /root/reference/src/main.cpp:778-791. */
+int rsr_rccl_probe(void);
 
 /* RealSR::process restricted to the tiles [tile_begin, tile_end) of the image's tile grid, counted row-major (tile (yi, xi) =
  * yi * ceil(w / tilesize) + xi; tiles are independent: realsr.cpp:377-380,458-459,490).  `in` is the whole image, `out` the
@@ -239,6 +246,16 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                         1 skip LDS-DMA (64: weights only, 128: patches only), 4 skip epilogue stores, 32 MFMA waves do not skip rows
  *                         outside the tile / inside the unread frame, 8192 conv_last never writes the uint8 image itself, 16384 no split tail for early download */
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
+
+/* Engine state, read-only (tests and measurement scripts; no reference counterpart).  key:
+ *   "plan_batches" / "plan_slots_per_batch"  tile batches / slots per batch of the most recently used plan (a 4K frame at tile 400
+ *                       fits ONE batch of 60 slots under the default 64 GiB budget; max_workspace_mb splits it), "plans" cached plans
+ *   "workspace_mb"      device memory the workspace holds, "ws_clamp_mb" the bound a failed allocation left behind (-1 = none)
+ *   "lanes", "lane_in_mb", "lane_out_mb"   rsr_process lanes created so far and the device image buffers they hold (a member of
+ *                       rsr_process_group allocates only the output rows of its tile range)
+ *   "last_test_us"      HIP-event time of the last rsr_conv3x3 / rsr_conv3x3_res launch (with option "test_repeat" = N the
+ *                       work items are repeated N times in that one launch: an L2-resident workload) */
+int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value);
 
 const char* rsr_last_error(const rsr_ctx* ctx); /* ctx may be NULL: last global (create/pack) error */
 const char* rsr_version(void);

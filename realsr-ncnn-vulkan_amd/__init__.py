@@ -25,7 +25,7 @@ EXPORTS = [
     "rsr_postproc_tta", "rsr_net_forward", "rsr_conv3x3", "rsr_set_profiling", "rsr_get_profile", "rsr_get_conv_times", "rsr_get_trace",
     "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_host_alloc", "rsr_host_free",
     "rsr_set_progress_callback", "rsr_conv3x3_res", "rsr_create_group", "rsr_group_transport", "rsr_process_rows",
-    "rsr_process_group", "rsr_device_memory", "rsr_process_tiles", "rsr_tile_partition",
+    "rsr_process_group", "rsr_device_memory", "rsr_process_tiles", "rsr_tile_partition", "rsr_rccl_probe", "rsr_get_stat",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -110,6 +110,8 @@ def lib():
     L.rsr_get_conv_times.argtypes = [vp, C.POINTER(C.c_double), ip, ip]
     L.rsr_get_trace.argtypes = [vp, C.POINTER(C.c_ulonglong), ip]
     L.rsr_set_option.argtypes = [vp, cp, C.c_longlong]
+    L.rsr_get_stat.argtypes = [vp, cp, C.POINTER(C.c_double)]
+    L.rsr_rccl_probe.argtypes = []
     L.rsr_last_error.argtypes = [vp]
     L.rsr_last_error.restype = cp
     L.rsr_version.restype = cp
@@ -223,6 +225,12 @@ class RealSR:
 
     def set_option(self, key, value):
         self._ck(self._L.rsr_set_option(self._h, key.encode(), int(value)))
+
+    def get_stat(self, key):
+        """rsr_get_stat: read-only engine state ("plan_batches", "workspace_mb", "lane_out_mb", "last_test_us", ...)."""
+        v = C.c_double(0)
+        self._ck(self._L.rsr_get_stat(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def process(self, img, out=None, push_params=True):
         """out: optional preallocated (4h, 4w, c) uint8 array (e.g. PinnedArray(...).array)."""
@@ -354,6 +362,14 @@ def device_memory(gpuid=0):
     if rc != RSR_OK:
         raise RealSRError(rc, lib().rsr_last_error(None).decode())
     return f.value, t.value
+
+
+def rccl_probe():
+    """rsr_rccl_probe (host-only): None when librccl can be dlopen'ed with every entry point rsr_create_group's RCCL branch
+    calls, else the reason."""
+    L = lib()
+    rc = L.rsr_rccl_probe()
+    return None if rc == RSR_OK else L.rsr_last_error(None).decode()
 
 
 def create_group(gpuids, parampath, modelpath, tta_mode=False):

@@ -342,6 +342,36 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n)
     return RSR_OK;
 }
 
+int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value)
+{
+    if (!ctx || !key || !value) return RSR_E_ARG;
+    rsr::Engine& e = ctx->e;
+    std::lock_guard<std::mutex> lk(e.mu);
+    const std::string k(key);
+    auto lanes_bytes = [&](bool out) {
+        std::lock_guard<std::mutex> ll(e.lane_mu);
+        double n = 0;
+        for (const auto& l : e.lanes) n += double(out ? l->d_out.bytes : l->d_in.bytes);
+        return n;
+    };
+    if (k == "plan_batches") *value = e.plans.empty() ? 0.0 : double(e.plans.front().batches.size());
+    else if (k == "plan_slots_per_batch") *value = e.plans.empty() ? 0.0 : double(e.plans.front().slots_per_batch);
+    else if (k == "plans") *value = double(e.plans.size());
+    else if (k == "ws_clamp_mb") *value = e.ws_clamp_bytes < 0 ? -1.0 : double(e.ws_clamp_bytes) / 1048576.0;
+    else if (k == "workspace_mb")
+    {
+        double n = 0;
+        for (const rsr::DevBuf* wb : {&e.b_in, &e.b_fea, &e.b_rdb[0], &e.b_rdb[1], &e.b_rdb[2], &e.b_up1, &e.b_up2, &e.b_hr, &e.b_out3}) n += double(wb->bytes);
+        *value = n / 1048576.0;
+    }
+    else if (k == "lanes") { std::lock_guard<std::mutex> ll(e.lane_mu); *value = double(e.lanes.size()); }
+    else if (k == "lane_out_mb") *value = lanes_bytes(true) / 1048576.0;
+    else if (k == "lane_in_mb") *value = lanes_bytes(false) / 1048576.0;
+    else if (k == "last_test_us") *value = e.last_test_us;
+    else return e.fail(RSR_E_ARG, "unknown stat " + k);
+    return RSR_OK;
+}
+
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
 {
     if (!ctx || !key) return RSR_E_ARG;
@@ -402,6 +432,13 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         ctx->e.alternate_order = value != 0;
     else if (k == "dbg")
         ctx->e.dbg = int(value);
+    else if (k == "test_repeat")
+    {
+        if (value < 1 || value > 100000) return ctx->e.fail(RSR_E_ARG, "test_repeat out of range");
+        ctx->e.test_repeat = int(value);
+    }
+    else if (k == "ws_clamp_mb") // test hook: what a failed workspace allocation leaves behind (enqueue_image's retry); < 0 clears it
+        ctx->e.ws_clamp_bytes = value < 0 ? -1 : value * 1048576;
     else if (k == "num_cu")
     {
         if (value < 8 || value > 1024) return ctx->e.fail(RSR_E_ARG, "num_cu out of range");

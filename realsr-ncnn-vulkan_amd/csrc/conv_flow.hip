@@ -675,8 +675,9 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         return w;
     };
 
-    // A block whose four rows of THIS wave lie wholly below the tile (tile heights are multiples of 4 at every level, blocks of
-    // 16: a 220-row tile ends in the block's third wave, a 100-row tile in its first) -- or wholly inside the frame of output
+    // A block whose four rows of THIS wave lie wholly below the tile (blocks of 16 rows: a 220-row tile ends in its last block's
+    // third wave, a 100-row tile in the first; any height works -- a 101-row tile keeps one row of the second wave alive and
+    // row_store drops the other three) -- or wholly inside the frame of output
     // pixels nothing downstream reads (ConvArgs::margin) -- does no matrix work here: the wave only
     // keeps the workgroup's barrier cadence -- one per half-stage -- fetches the descriptor the live path would fetch, and
     // reloads the operands of the next block's first step.  16 x 32 block quantisation otherwise costs 5.4 % of the MFMA

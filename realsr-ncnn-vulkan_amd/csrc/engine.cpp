@@ -155,6 +155,13 @@ hipEvent_t Engine::take_event()
     return e;
 }
 
+hipEvent_t Engine::take_event_timed()
+{
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
 void Engine::give_event(hipEvent_t e)
 {
     if (e) sync_events.push_back(e);
@@ -353,11 +360,33 @@ static hipError_t upload_batch(Plan::Batch& b, char*& d, bool xcd_order = true)
 static constexpr long long kBytesPerPx = 64 + 128 + 3 * 384 + 512 + 2048 + 2048 + 96;
 static constexpr size_t kMaxPlans = 8;
 
+// What the device can give this engine's workspace right now: 90 % of (free memory + the workspace it already holds) minus the
+// image buffers its lanes may still allocate (in + 16x out per lane; what they hold already is not free any more).  < 0: unknown.
+long long Engine::device_avail(int w, int h, int c)
+{
+    size_t f = 0, t = 0;
+    if (hipMemGetInfo(&f, &t) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return -1;
+    }
+    long long held = 0;
+    for (const DevBuf* wb : {&b_in, &b_fea, &b_rdb[0], &b_rdb[1], &b_rdb[2], &b_up1, &b_up2, &b_hr, &b_out3}) held += (long long)wb->bytes;
+    long long lanes_have = 0;
+    {
+        std::lock_guard<std::mutex> ll(lane_mu);
+        for (const auto& l : lanes) lanes_have += (long long)(l->d_in.bytes + l->d_out.bytes);
+    }
+    const long long lanes_need = std::max<long long>(0, (long long)max_lanes * 17 * w * h * c - lanes_have);
+    return std::max<long long>(0, ((long long)f + held) / 10 * 9 - lanes_need);
+}
+
 int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
 {
     for (auto it = plans.begin(); it != plans.end(); ++it)
         if (it->w == w && it->h == h && it->c == c && it->T == tilesize && it->P == prepadding && it->tta == tta &&
-            it->tile0 == tile0 && it->tile1 == tile1 && it->budget_mb == max_workspace_mb && it->trim == trim_tail && it->xcd_order == xcd_order)
+            it->tile0 == tile0 && it->tile1 == tile1 && it->budget_mb == max_workspace_mb && it->trim == trim_tail && it->xcd_order == xcd_order &&
+            it->clamp == ws_clamp_bytes)
         {
             plans.splice(plans.begin(), plans, it); // most recently used first
             out = &plans.front();
@@ -407,17 +436,8 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
     // of its lanes -- and never more than a size that has already failed to allocate (ws_clamp_bytes, enqueue_image's retry).
     long long budget = max_workspace_mb * 1024 * 1024;
     {
-        size_t f = 0, t = 0;
-        if (hipMemGetInfo(&f, &t) == hipSuccess)
-        {
-            long long held = 0;
-            for (const DevBuf* wb : {&b_in, &b_fea, &b_rdb[0], &b_rdb[1], &b_rdb[2], &b_up1, &b_up2, &b_hr, &b_out3}) held += (long long)wb->bytes;
-            const long long lanes_need = (long long)max_lanes * 17 * w * h * c;
-            const long long avail = ((long long)f + held) / 10 * 9 - lanes_need;
-            budget = std::min(budget, std::max<long long>(avail, per_slot * per));
-        }
-        else
-            (void)hipGetLastError();
+        const long long avail = device_avail(w, h, c);
+        if (avail >= 0) budget = std::min(budget, std::max<long long>(avail, per_slot * per));
     }
     if (ws_clamp_bytes >= 0) budget = std::min(budget, std::max<long long>(ws_clamp_bytes, per_slot * per));
     long long budget_slots = budget / std::max<long long>(per_slot, 1);
@@ -432,6 +452,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
     plan.budget_mb = max_workspace_mb;
     plan.trim = trim_tail;
     plan.xcd_order = xcd_order;
+    plan.clamp = ws_clamp_bytes;
     plan.cap_px = cap;
     plan.max_tw = mtw;
     plan.max_th = mth;
@@ -651,8 +672,9 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         a.dbg = dbg;
         a.trace = (trace_conv == ci) ? static_cast<unsigned long long*>(trace_buf.p) : nullptr;
         a.s1 = a.s2 = 1.f;
-        // x4.param order: ... RDB 69 (ci 341..345) | trunk_conv 346 | upconv1 347 | upconv2 348 | HRconv 349 | conv_last 350
-        a.margin = tail_margin(b.trim4, ci >= 347 ? 350 - ci : 4 + (346 - ci));
+        // x4.param order: ... RDB 69 | trunk_conv kNumConvs-5 | upconv1 -4 | upconv2 -3 | HRconv -2 | conv_last kNumConvs-1
+        constexpr int kLast = kNumConvs - 1, kUp1 = kNumConvs - 4;
+        a.margin = tail_margin(b.trim4, ci >= kUp1 ? kLast - ci : 4 + (kUp1 - 1 - ci));
         return a;
     };
     auto go = [&](ConvArgs& a) {
@@ -784,6 +806,10 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
     const int xtiles = (w + tilesize - 1) / tilesize;
     if (tile1 < 0) tile1 = xtiles * ((h + tilesize - 1) / tilesize);
     int rc;
+    // A clamp left behind by a transient allocation failure (another process held the memory for a moment) must not halve the
+    // batches for ever: when a NEW call finds that the device can give twice the clamped size again, it plans without it
+    // (never inside the retry loop below, which would then oscillate).  Plans are keyed by the clamp.
+    if (ws_clamp_bytes >= 0 && device_avail(w, h, c) >= 2 * ws_clamp_bytes) ws_clamp_bytes = -1;
     for (;;)
     {
         rc = get_plan(w, h, c, tile0, tile1, planp);
@@ -796,10 +822,15 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         const std::string why = last_error();
         const long long half_slots = std::max<long long>(per, (planp->slots_per_batch / 2) / per * per);
         ws_clamp_bytes = half_slots * planp->cap_px * kBytesPerPx;
+        if (!clamp_logged)
+        {
+            clamp_logged = true;
+            std::fprintf(stderr, "realsr-hip: workspace of %d tile slots does not fit device %d (%s); batches halved to %lld slots\n",
+                         planp->slots_per_batch, device, why.c_str(), half_slots);
+        }
         free_workspace(st); // partly grown buffers go back first; the stream is drained, so the plan's tables are idle too
         if (planp->d_tables) (void)hipFree(planp->d_tables);
         plans.pop_front(); // get_plan put it in front
-        (void)why;
     }
     if (rc != RSR_OK) return rc;
     const Plan& plan = *planp;
@@ -1011,7 +1042,16 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     }
     int rc;
     if ((rc = ensure(L->d_in, nin)) != RSR_OK) return rc;  // lane-private: nothing else can be using the old allocation
-    if ((rc = ensure(L->d_out, nout_full)) != RSR_OK) return rc;
+    // The device output holds only the output ROWS of this call's tile range (a member of rsr_process_group running an eighth
+    // of a 4K frame does not allocate 398 MB for it): the kernels get the address row 0 would have and only ever write
+    // inside the rectangles of the range's tiles (conv_last / postproc_tiles place by tile), i.e. inside the allocation.
+    const size_t rowbytes = size_t(w) * scale * c; // one output row
+    auto yof = [&](int tr) { return size_t(std::min(tr * T, h)) * scale; };  // first output row of tile row tr
+    auto xof = [&](int tc) { return size_t(std::min(tc * T, w)) * scale * c; }; // byte column of tile column tc
+    const int r0 = tile0 / xtiles, c0 = tile0 % xtiles, r1 = (tile1 - 1) / xtiles, c1 = (tile1 - 1) % xtiles + 1; // last tile = (r1, c1 - 1)
+    const size_t base_off = yof(r0) * rowbytes;
+    if ((rc = ensure(L->d_out, (yof(r1 + 1) - yof(r0)) * rowbytes)) != RSR_OK) return rc;
+    char* const vout = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(L->d_out.p) - base_off); // where output row 0 would be
 
     // ---- upload ----
     const void* src = in;
@@ -1031,7 +1071,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
         if (!loaded || scale != 4 || tilesize != T)
             return fail(RSR_E_STATE, "context parameters changed while the call was in flight"); // (the guard drains the upload)
         HIP_TRY(hipStreamWaitEvent(stream, L->ev_in, 0));
-        rc = enqueue_image(L->d_in.p, w, h, c, L->d_out.p, stream, tile0, tile1, L->ev_half, &half_rows);
+        rc = enqueue_image(L->d_in.p, w, h, c, vout, stream, tile0, tile1, L->ev_half, &half_rows);
         if (rc != RSR_OK)
         {
             (void)hipStreamSynchronize(stream); // kernels of this call that did get enqueued use the lane buffers
@@ -1042,34 +1082,59 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     }
 
     // ---- download ----
-    const size_t rowbytes = size_t(w) * scale * c; // one output row
-    auto yof = [&](int tr) { return size_t(std::min(tr * T, h)) * scale; };  // first output row of tile row tr
-    auto xof = [&](int tc) { return size_t(std::min(tc * T, w)) * scale * c; }; // byte column of tile column tc
-    const int r0 = tile0 / xtiles, c0 = tile0 % xtiles, r1 = (tile1 - 1) / xtiles, c1 = (tile1 - 1) % xtiles + 1; // last tile = (r1, c1 - 1)
     if (c0 != 0 || c1 != xtiles)
-    { // general tile range: up to three rectangles, straight into the caller's buffer (pinned or not)
+    { // general tile range: up to three rectangles.  Pinned destinations receive them directly; pageable ones through the
+      // lane's pinned staging, in row chunks (the CPU copy of chunk i under the PCIe transfer of chunk i+1), like whole rows below
         HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_done, 0));
-        const char* dsrc = static_cast<const char*>(L->d_out.p);
-        auto rect = [&](size_t y_a, size_t y_b, size_t x_a, size_t x_b) -> hipError_t {
-            if (y_b <= y_a || x_b <= x_a) return hipSuccess;
-            const size_t off = y_a * rowbytes + x_a;
-            return hipMemcpy2DAsync(out + off, rowbytes, dsrc + off, rowbytes, x_b - x_a, y_b - y_a, hipMemcpyDeviceToHost, L->copy);
+        const bool pinned = is_pinned_host(out);
+        const size_t CH = std::max<size_t>(chunk_bytes, 1 << 20);
+        if (!pinned && (rc = ensure_pinned(L->h_out, L->h_out_bytes, 2 * std::min(CH, nout_full))) != RSR_OK) return rc;
+        auto rect = [&](size_t y_a, size_t y_b, size_t x_a, size_t x_b) -> int {
+            if (y_b <= y_a || x_b <= x_a) return RSR_OK;
+            const size_t wb = x_b - x_a;
+            if (pinned)
+            {
+                const size_t off = y_a * rowbytes + x_a;
+                HIP_TRY(hipMemcpy2DAsync(out + off, rowbytes, vout + off, rowbytes, wb, y_b - y_a, hipMemcpyDeviceToHost, L->copy));
+                return RSR_OK;
+            }
+            const size_t half = L->h_out_bytes / 2, rows_per = std::max<size_t>(1, half / wb);
+            if (wb > half) return fail(RSR_E_ARG, "chunk_mb smaller than one output row");
+            const size_t nch = (y_b - y_a + rows_per - 1) / rows_per;
+            for (size_t i = 0; i <= nch; i++)
+            {
+                if (i < nch)
+                {
+                    const size_t ya = y_a + i * rows_per, nr = std::min(rows_per, y_b - ya);
+                    HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(L->h_out) + (i & 1) * half, wb, vout + ya * rowbytes + x_a, rowbytes, wb, nr,
+                                             hipMemcpyDeviceToHost, L->copy));
+                    HIP_TRY(hipEventRecord(L->ev_chunk[i & 1], L->copy));
+                }
+                if (i >= 1)
+                {
+                    const size_t k = i - 1, ya = y_a + k * rows_per, nr = std::min(rows_per, y_b - ya);
+                    HIP_TRY(hipEventSynchronize(L->ev_chunk[k & 1]));
+                    const char* sp = static_cast<const char*>(L->h_out) + (k & 1) * half;
+                    for (size_t y = 0; y < nr; y++) std::memcpy(out + (ya + y) * rowbytes + x_a, sp + y * wb, wb);
+                }
+            }
+            return RSR_OK;
         };
-        if (r0 == r1) HIP_TRY(rect(yof(r0), yof(r0 + 1), xof(c0), xof(c1)));
+        if (r0 == r1) { if ((rc = rect(yof(r0), yof(r0 + 1), xof(c0), xof(c1))) != RSR_OK) return rc; }
         else
         {
             int full0 = r0, full1 = r1 + 1; // whole tile rows [full0, full1)
             if (c0 != 0)
             {
-                HIP_TRY(rect(yof(r0), yof(r0 + 1), xof(c0), rowbytes));
+                if ((rc = rect(yof(r0), yof(r0 + 1), xof(c0), rowbytes)) != RSR_OK) return rc;
                 full0 = r0 + 1;
             }
             if (c1 != xtiles)
             {
-                HIP_TRY(rect(yof(r1), yof(r1 + 1), 0, xof(c1)));
+                if ((rc = rect(yof(r1), yof(r1 + 1), 0, xof(c1))) != RSR_OK) return rc;
                 full1 = r1;
             }
-            HIP_TRY(rect(yof(full0), yof(full1), 0, rowbytes));
+            if ((rc = rect(yof(full0), yof(full1), 0, rowbytes)) != RSR_OK) return rc;
         }
         HIP_TRY(hipStreamSynchronize(L->copy));
         return RSR_OK;
@@ -1082,7 +1147,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     const bool pinned_out = is_pinned_host(out);
     if (pinned_out)
     {
-        const char* dsrc = static_cast<const char*>(L->d_out.p) + out_off;
+        const char* dsrc = vout + out_off;
         if (first)
         {
             HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_half, 0));
@@ -1098,7 +1163,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     if ((rc = ensure_pinned(L->h_out, L->h_out_bytes, 2 * std::min(CH, nout))) != RSR_OK) return rc;
     const size_t half = L->h_out_bytes / 2;
     const size_t nchunks = (nout + half - 1) / half;
-    const char* dsrc = static_cast<const char*>(L->d_out.p) + out_off;
+    const char* dsrc = vout + out_off;
     bool waited_done = false;
     for (size_t i = 0; i <= nchunks; i++)
     {
@@ -1207,8 +1272,11 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     }
     DevBuf d_w, d_in, d_out, d_tab, d_res;
     std::vector<WorkItem> items;
-    for (int y0 = 0; y0 < H; y0 += kBlkH)
-        for (int x0 = 0; x0 < W; x0 += kBlkW) items.push_back(WorkItem{0, y0, x0, H, W, 0, 0, 0});
+    // test_repeat > 1 (measurement aid): the same blocks N times in ONE launch -- after the first pass every patch and every
+    // output line is in the L2s, i.e. the launch shows what this conv costs when nothing goes to HBM (tools/l2_bound_probe.py)
+    for (int rep = 0; rep < std::max(1, test_repeat); rep++)
+        for (int y0 = 0; y0 < H; y0 += kBlkH)
+            for (int x0 = 0; x0 < W; x0 += kBlkW) items.push_back(WorkItem{0, y0, x0, H, W, 0, 0, 0});
     const TileDim td{h, w};
     auto cleanup = [&]() {
         for (DevBuf* b : {&d_w, &d_in, &d_out, &d_tab, &d_res})
@@ -1263,8 +1331,15 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         a.dims = static_cast<const TileDim*>(d_tab.p);
         a.zeros = zeros.p;
         a.dbg = dbg;
+        hipEvent_t e0 = take_event_timed(), e1 = take_event_timed();
+        if (e0) (void)hipEventRecord(e0, stream);
         if (!launch_conv_flow(a, nt, num_cu, flow_flags, stream)) rc = fail(RSR_E_STATE, "conv3x3_flow: no variant");
+        if (e1) (void)hipEventRecord(e1, stream);
         he = hipStreamSynchronize(stream);
+        float ms = 0.f;
+        if (e0 && e1 && he == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) last_test_us = double(ms) * 1e3;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
         if (he == hipSuccess) he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpy(hout.data(), d_out.p, hout.size() * 2, hipMemcpyDeviceToHost);
     }

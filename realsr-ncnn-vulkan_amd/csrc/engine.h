@@ -43,6 +43,7 @@ struct Plan
     int tile0 = 0, tile1 = 0; // tiles [tile0, tile1) of the image's tile grid, row-major (multi-GPU tile sharding)
     long long budget_mb = 0;
     bool trim = true, xcd_order = true;
+    long long clamp = -1; // Engine::ws_clamp_bytes when the plan was built (part of the cache key)
     long long cap_px = 0; // slot capacity in LR pixels
     int max_tw = 0, max_th = 0;
     struct Batch
@@ -111,10 +112,14 @@ struct Engine
     bool trim_tail = true; // leave out the blocks / rows behind the trunk that only feed cropped output pixels (engine.cpp: tail_margin)
     bool xcd_order = true; // backward work-item tables reversed per XCD share (each XCD re-reads what IT wrote last: L2 hits), else as a whole
     bool alternate_order = true; // odd convs walk the work items backwards: they start on the data the previous conv touched last
+    int test_repeat = 1;        // conv_test: work items repeated N times in one launch (measurement aid)
+    double last_test_us = 0.0;  // HIP-event time of the last conv_test launch
     int trace_conv = -1; // conv index whose launch records s_memtime stamps into trace_buf (profiling only)
     DevBuf trace_buf;
     long long max_workspace_mb = 65536;
-    long long ws_clamp_bytes = -1; // set after a workspace allocation failed: the next plans stay below it (-1 = none)
+    long long ws_clamp_bytes = -1; // set after a workspace allocation failed: the next plans stay below it (-1 = none); dropped
+                                   // again when the device can give twice that much (get_plan)
+    bool clamp_logged = false;     // the halving is reported on stderr once per context
     int tail_group_slots = 0; // slots per launch group of the 2x / 4x convs (0 = the whole batch at once), see run_network
     int max_lanes = 4;
     size_t chunk_bytes = size_t(16) << 20; // download chunk for pageable destinations
@@ -180,6 +185,7 @@ struct Engine
     int ensure(DevBuf& b, size_t bytes);
     int ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool layout_changed, bool zero_all, hipStream_t st);
     int get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out);
+    long long device_avail(int w, int h, int c);
     void free_workspace(hipStream_t st);
     int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
     int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out = nullptr, int fused_out_w = 0, int split_slot = 0,
@@ -192,6 +198,7 @@ struct Engine
     void collect_profile(hipStream_t st);
     void free_plans();
     hipEvent_t take_event();
+    hipEvent_t take_event_timed(); // caller destroys
     void give_event(hipEvent_t e);
     Lane* acquire_lane(); // lane_mu inside
     void release_lane(Lane* l);

@@ -8,8 +8,13 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -59,6 +64,56 @@ struct Rccl
 };
 
 thread_local std::string g_transport = "none";
+
+// Worker threads of rsr_process_group, kept between calls (one image = one call: starting `parts` fresh threads per image
+// costs as much as a few tiles).  A worker is added only when a job finds none idle; the calling thread always runs share 0 itself.
+struct SharePool
+{
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::vector<std::thread> workers;
+    int idle = 0;
+    bool stop = false;
+    void run(std::function<void()> f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            q.push_back(std::move(f));
+            if (int(q.size()) > idle && workers.size() < 64) // nobody free for this job: one more worker (64 = more GPUs than a node has)
+                workers.emplace_back([this] {
+                    std::unique_lock<std::mutex> lk(m);
+                    for (;;)
+                    {
+                        idle++;
+                        cv.wait(lk, [this] { return stop || !q.empty(); });
+                        idle--;
+                        if (q.empty()) return;
+                        std::function<void()> job = std::move(q.front());
+                        q.pop_front();
+                        lk.unlock();
+                        job();
+                        lk.lock();
+                    }
+                });
+        }
+        cv.notify_one();
+    }
+    ~SharePool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (std::thread& t : workers) t.join();
+    }
+};
+SharePool& share_pool()
+{
+    static SharePool p;
+    return p;
+}
 
 // dst[i] (device i, `bytes` each) <- src on device gpuids[0], one broadcast.  false + why on any failure.
 bool rccl_broadcast(const int* gpuids, int n, const void* src, void* const* dst, size_t bytes, std::string& why)
@@ -155,7 +210,11 @@ int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, cons
     }
     g_transport = "host";
     bool done = false;
-    if (n > 1)
+    // One GPU needs no broadcast -- unless RSR_GROUP_FORCE_RCCL=1 asks for the collective anyway (a communicator of one rank, an
+    // in-place broadcast): the way to execute the whole RCCL branch -- dlopen, ncclCommInitAll, grouped ncclBroadcast, stream
+    // sync, ncclCommDestroy, load from the device copy -- on a single-GPU box.
+    const char* force = std::getenv("RSR_GROUP_FORCE_RCCL");
+    if (n > 1 || (force && force[0] == '1'))
     {
         // device staging buffers: blob on GPU 0, receive buffers on the others
         std::vector<void*> dbuf(size_t(n), nullptr);
@@ -202,6 +261,19 @@ int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, cons
 }
 
 const char* rsr_group_transport(void) { return g_transport.c_str(); }
+
+// Host-only: can the RCCL branch of rsr_create_group be taken at all?  dlopen + the entry points it calls, nothing else (no
+// communicator, no device).  0 = yes; RSR_E_DEVICE + rsr_last_error() = which step failed.
+int rsr_rccl_probe(void)
+{
+    Rccl r;
+    std::string why;
+    const bool ok = r.open(why);
+    if (ok && !r.GetErrorString) why = "librccl lacks ncclGetErrorString";
+    if (r.lib) dlclose(r.lib);
+    if (!ok || !why.empty()) return Engine::fail(RSR_E_DEVICE, why);
+    return RSR_OK;
+}
 
 int rsr_process_tiles(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out, int tile_begin, int tile_end)
 {
@@ -282,13 +354,25 @@ int rsr_process_group(rsr_ctx* const* ctx, int n, const uint8_t* in, int w, int 
     if (prc < 0) return prc;
     std::vector<int> rcs(size_t(parts), RSR_OK);
     std::vector<std::string> errs{size_t(parts)};
-    std::vector<std::thread> th;
-    for (int i = 0; i < parts; i++)
-        th.emplace_back([&, i] {
-            rcs[size_t(i)] = ctx[i]->e.process_host(in, w, h, c, out, bound[size_t(i)], bound[size_t(i) + 1]);
-            if (rcs[size_t(i)] != RSR_OK) errs[size_t(i)] = rsr::last_error();
+    auto share = [&](int i) {
+        rcs[size_t(i)] = ctx[i]->e.process_host(in, w, h, c, out, bound[size_t(i)], bound[size_t(i) + 1]);
+        if (rcs[size_t(i)] != RSR_OK) errs[size_t(i)] = rsr::last_error();
+    };
+    // shares 1.. on the pool's threads, share 0 on the caller's; the call returns when all have reported
+    std::mutex dm;
+    std::condition_variable dcv;
+    int pending = parts - 1;
+    for (int i = 1; i < parts; i++)
+        share_pool().run([&, i] {
+            share(i);
+            std::lock_guard<std::mutex> lk(dm);
+            if (--pending == 0) dcv.notify_one();
         });
-    for (auto& t : th) t.join();
+    share(0);
+    {
+        std::unique_lock<std::mutex> lk(dm);
+        dcv.wait(lk, [&] { return pending == 0; });
+    }
     for (int i = 0; i < parts; i++)
         if (rcs[size_t(i)] != RSR_OK) return Engine::fail(rcs[size_t(i)], "gpu share " + std::to_string(i) + ": " + errs[size_t(i)]);
     return RSR_OK;

@@ -163,6 +163,27 @@ def test_tile_partition_balances_one_image_over_the_gpus():
         R.tile_partition(0, 10, 32, 10, 2)
 
 
+def test_rccl_probe_resolves_the_collective_without_a_gpu():
+    """rsr_rccl_probe (host-only): the RCCL branch of rsr_create_group starts with dlopen(librccl) + six entry points
+    (group.cpp).  The ROCm image carries librccl, so the probe must succeed in the GPU-less container too -- and creating the
+    group itself must still fail loudly there (no device), whatever RSR_GROUP_FORCE_RCCL says."""
+    assert R.rccl_probe() is None
+    import torch
+    if not torch.cuda.is_available():
+        env_before = os.environ.get("RSR_GROUP_FORCE_RCCL")
+        os.environ["RSR_GROUP_FORCE_RCCL"] = "1"
+        try:
+            d = synth.make_model_dir(os.environ.get("RSR_MODELS", "/tmp/rsr_models"), "models-DF2K", 42)
+            with pytest.raises(R.RealSRError) as e:
+                R.create_group([0], os.path.join(d, "x4.param"), os.path.join(d, "x4.bin"))
+            assert e.value.code == R.RSR_E_DEVICE
+        finally:
+            if env_before is None:
+                del os.environ["RSR_GROUP_FORCE_RCCL"]
+            else:
+                os.environ["RSR_GROUP_FORCE_RCCL"] = env_before
+
+
 def test_shard_frames_partitions_exactly():
     for n, ws in [(64, 8), (7, 4), (1, 2), (0, 3)]:
         seen = sorted(i for r in range(ws) for i in R.shard_frames(n, ws, r))
@@ -177,3 +198,24 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_real_model_harness_skips_without_a_blob_and_runs_host_checks(model_dir, tmp_path):
+    """tools/check_real_model.py: with no x4.bin anywhere it reports SKIP and exits 0; on a model directory it identifies the
+    encoding by size (33,424,520 B fp16-tagged / 66,793,352 B raw fp32, SURVEY a-7), packs, and walks the graph in fp32 for the
+    fp16 activation-range guard -- the walk must agree with the oracle's own .param interpreter.  (GPU legs: -m gpu.)"""
+    import json
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_real_model.py")
+    env = dict(os.environ)
+    env.pop("RSR_REAL_MODELS", None)
+    r = subprocess.run([sys.executable, tool, str(tmp_path)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("SKIP"), r.stdout + r.stderr
+    out = tmp_path / "rep.json"
+    r = subprocess.run([sys.executable, tool, model_dir, "--no-gpu", "--json", str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RESULT: ok" in r.stdout, r.stdout + r.stderr
+    rep = json.loads(out.read_text())
+    assert rep["encoding_by_size"] == rep["encoding_by_parser"] == "fp16-tagged" and rep["bin_bytes"] == 33424520
+    assert rep["walk_vs_oracle_max"] < 1e-4 and len(rep["activation_peaks"]) == 1 + 69 + 4
+    assert 1.0 < max(v for _, v in rep["activation_peaks"]) < 65504

@@ -133,6 +133,12 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef RSR_FLOW_LIFE // experiment builds only (tools/flow_life.py): per-workgroup s_memtime stamps -- entry, first half-stage in LDS, exit
+    const unsigned long long life_t0 = __builtin_amdgcn_s_memtime();
+#define RSR_LIFE(SLOT) if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + (SLOT)] = __builtin_amdgcn_s_memtime();
+#else
+#define RSR_LIFE(SLOT)
+#endif
     const int nst = a.n0 + a.n1; // half-stages per block (16-channel planes), even by construction (engine pads)
     // ring depths and LDS offsets: compile-time constants when the weights are streamed
     const int PR = WRES ? a.pr : C::PR, WR = WRES ? nst : C::WR;
@@ -146,6 +152,11 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     if (nmine == 0) return;
     const int S = nmine * nst;
 
+    // Launch prologue (measured, round 4: tools/flow_life.py, profiles/r04_ab_prologue.txt): 5 - 7 us from kernel entry to the first
+    // half-stage in LDS -- this bias round trip, a cold descriptor load, then every weight image ahead of the first patch.  A build
+    // that brought the bias in by LDS-DMA (no barrier here), issued W(0) ahead of the descriptor and interleaved the other images
+    // with the first block's patches cut 1.5 - 2.6 us of it per launch and did NOT shorten the frame (+0.3 %): under the 1,400 W cap
+    // the frame is bound by energy, idle microseconds are not the resource.  Kept as it was.
     if (tid < NT * 32) reinterpret_cast<float*>(smem + kBiasOff)[tid] = a.bias[tid];
     __syncthreads();
 
@@ -714,6 +725,10 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     (void)t_rel;
     if (tracing) t_arr = __builtin_amdgcn_s_memtime();
     asm volatile("s_barrier" ::: "memory"); // E_0: half-stage 0 is in LDS
+#ifdef RSR_FLOW_LIFE
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 0] = life_t0;
+    RSR_LIFE(1)
+#endif
     if (tracing && lane == 0)
     {
         a.trace[0] = t_arr;
@@ -807,6 +822,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         }
 #undef RSR_HALF3
 #undef RSR_M6
+        RSR_LIFE(2)
         return;
     }
     {
@@ -1000,6 +1016,8 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #undef RSR_BLOCK
 #include "conv_flow_hooks_undef.inc"
     }
+    RSR_LIFE(2)
+#undef RSR_LIFE
 #undef RSR_HALF_PLAIN
 #undef RSR_HALF
 #undef RSR_IDTAP

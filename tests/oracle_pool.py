@@ -16,12 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _NET = None
 
 
-def _init(pp, bp, threads):
+def _init(pp, bp, threads, child=True):
     global _NET
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["RSR_NO_TORCH"] = "1"
+    if child:  # a CPU-only worker process never needs torch; the calling process must not inherit the switch (its own
+        os.environ["RSR_NO_TORCH"] = "1"  # subprocesses -- bench.py, tools/ -- would load the wrong HIP runtime first)
     import oracle
     _NET = oracle.OracleNet(pp, bp)
     oracle.set_threads(threads)
@@ -85,7 +86,7 @@ def ref_tiles(pp, bp, jobs, P=10, threads=16, workers=None):
         workers = int(os.environ.get("RSR_ORACLE_WORKERS", "0")) or max(1, min(len(jobs), cpus // threads, 12))
     threads = max(1, min(threads, cpus))
     if workers <= 1:
-        _init(pp, bp, threads)
+        _init(pp, bp, threads, child=False)
         return [_one(j) for j in jobs]
     ctx = mp.get_context("spawn")  # never fork a process that holds a HIP context
     with ctx.Pool(workers, initializer=_init, initargs=(pp, bp, threads)) as pool:

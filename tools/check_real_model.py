@@ -192,6 +192,11 @@ def main():
     ap.add_argument("--no-bench", action="store_true")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
+    if not args.no_gpu:
+        # PyTorch's bundled HIP runtime has to be the first one in the process (realsr-ncnn-vulkan_amd/__init__.py: lib()); an
+        # inherited RSR_NO_TORCH=1 (the oracle worker pool sets it for its CPU-only children) would load /opt/rocm's copy first
+        os.environ.pop("RSR_NO_TORCH", None)
+        import torch  # noqa: F401
     d = find_model_dir(args.dir)
     if d is None:
         print("SKIP: no x4.param + x4.bin found%s (the reference checkout ships x4.param only: .MISSING_LARGE_BLOBS)" % (

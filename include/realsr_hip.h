@@ -244,7 +244,8 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                       starts on the blocks IT wrote last (its own 4 MB L2); 0: the list is reversed as a whole
  *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
  *                         1 skip LDS-DMA (64: weights only, 128: patches only), 4 skip epilogue stores, 32 MFMA waves do not skip rows
- *                         outside the tile / inside the unread frame, 8192 conv_last never writes the uint8 image itself, 16384 no split tail for early download */
+ *                         outside the tile / inside the unread frame, 8192 conv_last never writes the uint8 image itself, 16384 no split tail for early download,
+ *                         32768 / 65536 force the one-thread-per-pixel / the LDS-staged pre and post kernels (default: chosen per launch) */
 int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
 
 /* Engine state, read-only (tests and measurement scripts; no reference counterpart).  key:

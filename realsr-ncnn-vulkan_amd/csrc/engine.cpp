@@ -850,6 +850,7 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         pa.slot_stride = (32 / pc) * (plan.cap_px * pc * 2 + kGuard);
         pa.bgr = bgr ? 1 : 0;
         pa.plane_ch = pc;
+        pa.variant = (dbg & 32768) ? 1 : ((dbg & 65536) ? 2 : 0);
         launch_preproc_tiles(pa, plan.max_tw, plan.max_th, st);
         mark(0, 0, b.px[0] / (tta ? 8 : 1) * c + b.px[0] * 64, st);
         // conv_last writes the uint8 image directly when no TTA merge / alpha channel needs the fp16 blob (dbg 8192: off)
@@ -883,6 +884,7 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         po.in_w = w; po.in_h = h;
         po.tilesize = tilesize;
         po.bgr = bgr ? 1 : 0;
+        po.variant = (dbg & 32768) ? 1 : ((dbg & 65536) ? 2 : 0);
         launch_postproc_tiles(po, (plan.max_tw - 2 * prepadding) * scale, (plan.max_th - 2 * prepadding) * scale, st);
         mark(2, 0, b.px[2] / (tta ? 8 : 1) * (6.0 * (tta ? 8 : 1) + c), st);
     }

@@ -112,6 +112,7 @@ struct PreArgs
     long long slot_stride;
     int bgr;
     int plane_ch;   // 16
+    int variant;    // 0 default (launch_preproc_tiles picks), 1 one thread per pixel (engine dbg 32768), 2 LDS-staged (dbg 65536)
 };
 void launch_preproc_tiles(const PreArgs& a, int max_tw, int max_th, hipStream_t st);
 
@@ -129,6 +130,7 @@ struct PostArgs
     int in_w, in_h;
     int tilesize;
     int bgr;
+    int variant; // 0 default (LDS-staged under TTA, else one thread per pixel), 1 per-pixel (engine dbg 32768), 2 LDS-staged (dbg 65536)
 };
 void launch_postproc_tiles(const PostArgs& a, int max_ow, int max_oh, hipStream_t st);
 

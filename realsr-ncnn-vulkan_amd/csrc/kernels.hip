@@ -1,7 +1,9 @@
 // kernels.hip -- gfx950 (CDNA4 / MI355X) pre/post kernels of the RealSR x4 hot path.
 //
-//   preproc_tiles          realsr_preproc{,_tta}.comp equivalent, writes the network input planes
-//   postproc_tiles         realsr_postproc{,_tta}.comp equivalent, writes the uint8 HWC image
+//   preproc_tiles[_lds]    realsr_preproc{,_tta}.comp equivalent, writes the network input planes
+//   postproc_tiles[_lds]   realsr_postproc{,_tta}.comp equivalent, writes the uint8 HWC image
+//                          (_lds: rows staged in LDS, dword loads / 1-KiB stores, transposed TTA variants through an LDS tile;
+//                          chosen per launch by measurement: launch_*_tiles)
 //   *_shader               the same arithmetic in the shaders' own memory layout (parity tests)
 //
 // The 351 convolutions live in conv_flow.hip (conv3x3_flow).  Written for gfx950 only.
@@ -79,11 +81,119 @@ __global__ __launch_bounds__(256) void preproc_tiles(const PreArgs a)
     }
 }
 
+// The same arithmetic with the memory traffic of realsr_preproc{,_tta}.comp reorganised for HBM (round 4; byte-identical to the
+// one-thread-per-pixel kernel above, which stays the default -- see launch_preproc_tiles):
+//   * one workgroup = a 32 x 32 block of padded-tile pixels.  Its source rows are staged in LDS with aligned DWORD loads, one
+//     wave per row (reflection folds the 32 columns of a block onto at most 32 source columns, i.e. <= 132 contiguous bytes);
+//   * the pixels are converted once (uint8 -> fp16 / 255) into an LDS tile [32][33] of (r, g, b) halfs;
+//   * every TTA variant is then written row by row of ITS OWN orientation: a wave stores 32 pixels x 32 B = 1 KiB of whole
+//     cache lines per instruction (lane = (pixel, 16-byte half)) -- also for the four transposed variants, whose rows run down
+//     the tile's columns (column reads of the LDS tile are conflict-free through the 33-pixel pitch).
+__global__ __launch_bounds__(256) void preproc_tiles_lds(const PreArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char raw[32][144];
+    __shared__ uint2 px[32][33];
+    const BaseTile t = a.tiles[blockIdx.z];
+    const int gx0 = blockIdx.x * 32, gy0 = blockIdx.y * 32;
+    if (gx0 >= t.tw || gy0 >= t.th) return;
+    const int nx = min(32, t.tw - gx0), ny = min(32, t.th - gy0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // source column span [lo, hi] of the block's columns (every wave computes it for itself)
+    int xs = reflect101(gx0 + min(lane & 31, nx - 1) + t.x_org, a.w);
+    int lo = xs, hi = xs;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1)
+    {
+        lo = min(lo, __shfl_xor(lo, d));
+        hi = max(hi, __shfl_xor(hi, d));
+    }
+    const long long total = (long long)a.w * a.h * a.c;
+    for (int r = wave; r < ny; r += 4)
+    {
+        const int y = reflect101(gy0 + r + t.y_org, a.h);
+        const long long b0 = ((long long)y * a.w + lo) * a.c, b1 = ((long long)y * a.w + hi + 1) * a.c;
+        const long long a0 = b0 & ~3ll;
+        const int nd = int((b1 - a0 + 3) >> 2); // <= 33 dwords
+        if (lane < nd)
+        {
+            const long long ad = a0 + 4 * lane;
+            uint32_t v;
+            if (ad + 4 <= total) v = *reinterpret_cast<const uint32_t*>(a.img + ad);
+            else
+            { // the last bytes of the image: never read past its end
+                v = 0;
+                for (int e = 0; e < 4; e++)
+                    if (ad + e < total) v |= (uint32_t)a.img[ad + e] << (8 * e);
+            }
+            *reinterpret_cast<uint32_t*>(&raw[r][4 * lane]) = v;
+        }
+    }
+    __syncthreads();
+    const float norm_val = 1 / 255.f;
+    const int i0 = a.bgr ? 2 : 0, i2 = a.bgr ? 0 : 2;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+        const int r = (tid >> 5) + 8 * m, cx = tid & 31;
+        if (r < ny && cx < nx)
+        {
+            const int x = reflect101(gx0 + cx + t.x_org, a.w);
+            const int y = reflect101(gy0 + r + t.y_org, a.h);
+            const int shift = int((((long long)y * a.w + lo) * a.c) & 3);
+            const unsigned char* p = &raw[r][shift + (x - lo) * a.c];
+            const _Float16 hr = (_Float16)((float)p[i0] * norm_val), hg = (_Float16)((float)p[1] * norm_val), hb = (_Float16)((float)p[i2] * norm_val);
+            uint2 v;
+            v.x = (uint32_t)__builtin_bit_cast(unsigned short, hr) | ((uint32_t)__builtin_bit_cast(unsigned short, hg) << 16);
+            v.y = (uint32_t)__builtin_bit_cast(unsigned short, hb);
+            px[r][cx] = v;
+        }
+    }
+    __syncthreads();
+    const int nv = a.tta ? 8 : 1;
+    const int pi = lane >> 1, half = lane & 1; // lane = (pixel of the output row, 16-byte half of its 32 B)
+    for (int k = 0; k < nv; k++)
+    {
+        const bool tr = k >= 4;                 // transposed variants: an output row runs down a tile column
+        const int nrow = tr ? nx : ny, ncol = tr ? ny : nx;
+        char* const base = static_cast<char*>(a.in_plane) + (long long)(t.slot0 + k) * a.slot_stride;
+        for (int ro = wave; ro < nrow; ro += 4)
+        {
+            if (pi >= ncol) continue;
+            const int r = tr ? pi : ro, cx = tr ? ro : pi;
+            const int gx = gx0 + cx, gy = gy0 + r;
+            int oy, ox, ow;
+            switch (k)
+            { // realsr_preproc_tta.comp:104-111
+            default: oy = gy; ox = gx; ow = t.tw; break;
+            case 1: oy = gy; ox = t.tw - 1 - gx; ow = t.tw; break;
+            case 2: oy = t.th - 1 - gy; ox = t.tw - 1 - gx; ow = t.tw; break;
+            case 3: oy = t.th - 1 - gy; ox = gx; ow = t.tw; break;
+            case 4: oy = gx; ox = gy; ow = t.th; break;
+            case 5: oy = gx; ox = t.th - 1 - gy; ow = t.th; break;
+            case 6: oy = t.tw - 1 - gx; ox = t.th - 1 - gy; ow = t.th; break;
+            case 7: oy = t.tw - 1 - gx; ox = gy; ow = t.th; break;
+            }
+            const uint2 v = px[r][cx];
+            const uint4 o = half ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(v.x, v.y, 0u, 0u);
+            *reinterpret_cast<uint4*>(base + ((long long)oy * ow + ox) * 32 + half * 16) = o;
+        }
+    }
+}
+
 void launch_preproc_tiles(const PreArgs& a, int max_tw, int max_th, hipStream_t st)
 {
     if (a.ntiles <= 0) return;
-    const dim3 grid((max_tw + 31) / 32, (max_th + 7) / 8, a.ntiles), block(256);
-    hipLaunchKernelGGL(preproc_tiles, grid, block, 0, st, a);
+    // Measured (tools/prepost_perf.py, profiles/r04_prepost.txt): 0.042 ms LDS-staged vs 0.032 ms per-pixel on a 1080p frame, 0.145 vs
+    // 0.150 ms with the 8 TTA scatters -- the byte loads of the plain kernel are served by the caches, its 32-byte stores are whole
+    // sectors: staging buys nothing here.  Default = the plain kernel; variant 2 forces the staged one (tests, A/B).
+    if (a.variant != 2 || a.plane_ch != 16 || (reinterpret_cast<uintptr_t>(a.img) & 3))
+    {
+        const dim3 grid((max_tw + 31) / 32, (max_th + 7) / 8, a.ntiles), block(256);
+        hipLaunchKernelGGL(preproc_tiles, grid, block, 0, st, a);
+        return;
+    }
+    const dim3 grid((max_tw + 31) / 32, (max_th + 31) / 32, a.ntiles), block(256);
+    hipLaunchKernelGGL(preproc_tiles_lds, grid, block, 0, st, a);
 }
 
 // store conversion of realsr_postproc.comp:71-78 (v + 0.5, floor, clamp 0..255); negative values
@@ -182,11 +292,139 @@ __global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
     }
 }
 
+// realsr_postproc{,_tta}.comp with coalesced traffic (round 4; byte-identical to the kernel above; the default under TTA):
+// one workgroup = a 32 x 32 block of the tile's kept output rectangle, 4 pixels per thread.  The four plain TTA variants are
+// read along their rows (lanes along x, forwards or backwards: contiguous either way).  The four TRANSPOSED variants store pixel
+// (sx, sy) at [sx][sy]: read naively, a wave touches 64 different cache lines for 128 useful bytes -- here each (variant,
+// channel) block is read along ITS rows into an LDS tile and picked up transposed (34-half pitch: conflict-free).  The merge keeps
+// the shader's summation order (v0 + v1 + ... + v7) * 0.125.  The uint8 pixels are collected in LDS and leave as aligned dwords
+// (a 32-pixel row segment of the HWC image = 96 or 128 contiguous bytes).
+__global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
+{
+    __shared__ _Float16 T[32][34];
+    __shared__ __attribute__((aligned(16))) unsigned char ob[32][128];
+    const BaseTile t = a.tiles[blockIdx.z];
+    const int gx0 = blockIdx.x * 32, gy0 = blockIdx.y * 32;
+    if (gx0 >= t.out_w || gy0 >= t.out_h) return;
+    const int nx = min(32, t.out_w - gx0), ny = min(32, t.out_h - gy0);
+    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
+    const int w = t.tw * 4, h = t.th * 4;
+    const long long cstep = (long long)w * h;
+    const _Float16* b0 = reinterpret_cast<const _Float16*>(static_cast<const char*>(a.planar3) + (long long)t.slot0 * a.slot_stride);
+    const long long ss = a.slot_stride / 2;
+    float acc[4][3];
+    const int sx = gx0 + lx + a.crop;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+        const int gyl = ly + 8 * m, sy = gy0 + gyl + a.crop;
+        const bool ok = lx < nx && gyl < ny;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+        {
+            float v = 0.f;
+            if (ok)
+            {
+                const _Float16* b = b0 + q * cstep;
+                v = (float)b[(long long)sy * w + sx];
+                if (a.tta)
+                { // realsr_postproc_tta.comp:76-79
+                    v += (float)b[ss + (long long)sy * w + (w - 1 - sx)];
+                    v += (float)b[2 * ss + (long long)(h - 1 - sy) * w + (w - 1 - sx)];
+                    v += (float)b[3 * ss + (long long)(h - 1 - sy) * w + sx];
+                }
+            }
+            acc[m][q] = v;
+        }
+    }
+    if (a.tta)
+    {
+        for (int k = 4; k < 8; k++)
+            for (int q = 0; q < 3; q++)
+            {
+                __syncthreads(); // the previous tile has been consumed
+                const _Float16* b = b0 + k * ss + q * cstep;
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                {
+                    const int ai = ly + 8 * m, bi = lx; // local (sx, sy) of the element this thread fetches: lanes along sy = along the row
+                    if (ai < nx && bi < ny)
+                    {
+                        const int ex = gx0 + ai + a.crop, ey = gy0 + bi + a.crop;
+                        long long off; // realsr_postproc_tta.comp:80-83
+                        if (k == 4) off = (long long)ex * h + ey;
+                        else if (k == 5) off = (long long)ex * h + (h - 1 - ey);
+                        else if (k == 6) off = (long long)(w - 1 - ex) * h + (h - 1 - ey);
+                        else off = (long long)(w - 1 - ex) * h + ey;
+                        T[ai][bi] = b[off];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                {
+                    const int gyl = ly + 8 * m;
+                    if (lx < nx && gyl < ny) acc[m][q] += (float)T[lx][gyl];
+                }
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+        const int gyl = ly + 8 * m;
+        if (!(lx < nx && gyl < ny)) continue;
+        float v[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) v[q] = a.tta ? acc[m][q] * 0.125f : acc[m][q];
+        unsigned char* o = &ob[gyl][lx * a.c];
+        o[a.bgr ? 2 : 0] = post_store(v[0] * 255.f);
+        o[1] = post_store(v[1] * 255.f);
+        o[a.bgr ? 0 : 2] = post_store(v[2] * 255.f);
+        if (a.c == 4)
+        { // alpha: bicubic x4 of the un-padded tile's alpha, exactly as in postproc_tiles
+            const int gx = gx0 + lx, gy = gy0 + gyl;
+            const int aw = t.out_w / 4, ah = t.out_h / 4;
+            const int ax0 = t.out_x / 4, ay0 = t.out_y / 4;
+            int bx, by;
+            float cx[4], cy[4];
+            cubic_coeffs(aw, t.out_w, gx, bx, cx);
+            cubic_coeffs(ah, t.out_h, gy, by, cy);
+            float rows[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int yy = ay0 + clampi(by - 1 + j, ah);
+                const uint8_t* rp = a.in_img + ((long long)yy * a.in_w + ax0) * 4 + 3;
+                rows[j] = (float)rp[clampi(bx - 1, aw) * 4] * cx[0] + (float)rp[clampi(bx, aw) * 4] * cx[1] +
+                          (float)rp[clampi(bx + 1, aw) * 4] * cx[2] + (float)rp[clampi(bx + 2, aw) * 4] * cx[3];
+            }
+            o[3] = post_store(rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3]);
+        }
+    }
+    __syncthreads();
+    const int nd = nx * a.c / 4; // out_w, gx0 are multiples of 4: a row segment is whole dwords, 4-byte aligned in the image
+    for (int i = tid; i < ny * nd; i += 256)
+    {
+        const int r = i / nd, d = i - r * nd;
+        uint8_t* o = a.out + ((long long)(t.out_y + gy0 + r) * a.out_w + t.out_x + gx0) * a.c;
+        reinterpret_cast<uint32_t*>(o)[d] = reinterpret_cast<const uint32_t*>(&ob[r][0])[d];
+    }
+}
+
 void launch_postproc_tiles(const PostArgs& a, int max_ow, int max_oh, hipStream_t st)
 {
     if (a.ntiles <= 0) return;
-    const dim3 grid((max_ow + 63) / 64, (max_oh + 3) / 4, a.ntiles), block(256);
-    hipLaunchKernelGGL(postproc_tiles, grid, block, 0, st, a);
+    // Measured (profiles/r04_prepost.txt): the TTA gather 0.92 ms staged vs 2.42 ms per-pixel on the C5 frame (2.26 vs 0.86 TB/s: the
+    // transposed variants), but 0.19 vs 0.12 ms for the plain single-variant conversion.  Default: staged under TTA, plain otherwise.
+    const bool staged = a.variant == 2 || (a.variant == 0 && a.tta);
+    if (!staged || (reinterpret_cast<uintptr_t>(a.out) & 3))
+    {
+        const dim3 grid((max_ow + 63) / 64, (max_oh + 3) / 4, a.ntiles), block(256);
+        hipLaunchKernelGGL(postproc_tiles, grid, block, 0, st, a);
+        return;
+    }
+    const dim3 grid((max_ow + 31) / 32, (max_oh + 31) / 32, a.ntiles), block(256);
+    hipLaunchKernelGGL(postproc_tiles_lds, grid, block, 0, st, a);
 }
 
 // ---- shader-shaped kernels: same arithmetic, the shaders' own buffer layouts -----------------

@@ -234,7 +234,8 @@ def test_c5_tta_against_oracle():
 def test_engine_options_do_not_change_the_bytes(paths, sr):
     """Scheduling / staging knobs (include/realsr_hip.h: rsr_set_option) are implementation details: tail launch groups,
     work-item order, one lane, single-threaded staging copies, small download chunks, no dead-output elimination, rows below
-    the tile computed, small tile batches -- every one must reproduce the default configuration's bytes, RGB, RGBA and TTA."""
+    the tile computed, small tile batches, the one-thread-per-pixel / the LDS-staged pre and post kernels forced (dbg 32768 / 65536;
+    with 8192 the RGB path runs postproc_tiles too) -- every one must reproduce the default configuration's bytes, RGB, RGBA and TTA."""
     imgs = [synth.make_image(61, 150, 100), synth.make_image(62, 70, 90, 4)]
     sr.tilesize = 32
     want = [sr.process(im) for im in imgs]
@@ -243,7 +244,7 @@ def test_engine_options_do_not_change_the_bytes(paths, sr):
     t.tilesize = 32
     want_tta = t.process(imgs[0])
     knobs = [("tail_group", 1, 0), ("tail_group", 3, 0), ("alternate_order", 0, 1), ("xcd_order", 0, 1), ("max_lanes", 1, 4), ("copy_threads", 1, 4), ("chunk_mb", 1, 16),
-             ("trim", 0, 1), ("dbg", 32, 0), ("dbg", 8192, 0), ("dbg", 16384, 0), ("flow_flags", 3, 0), ("flow_flags", 4, 0), ("max_workspace_mb", 64, 65536), ("num_cu", 64, 256)]
+             ("trim", 0, 1), ("dbg", 32, 0), ("dbg", 8192, 0), ("dbg", 16384, 0), ("dbg", 32768, 0), ("dbg", 65536, 0), ("dbg", 8192 | 65536, 0), ("flow_flags", 3, 0), ("flow_flags", 4, 0), ("max_workspace_mb", 64, 65536), ("num_cu", 64, 256)]
     try:
         for key, val, default in knobs:
             for ctx, ims, refs in ((sr, imgs, want), (t, imgs[:1], [want_tta])):
@@ -255,6 +256,48 @@ def test_engine_options_do_not_change_the_bytes(paths, sr):
                     ctx.set_option(key, default)
     finally:
         t.close()
+
+
+def test_lds_staged_pre_post_kernels_equal_the_per_pixel_ones(paths, sr):
+    """preproc_tiles_lds / postproc_tiles_lds (rows staged in LDS, dword loads, 1-KiB stores, transposed TTA variants through an
+    LDS tile; forced with dbg 65536, by default only the TTA gather runs staged) against the one-thread-per-pixel kernels (dbg
+    32768) -- same arithmetic, so the same BYTES: RGB through the
+    two-kernel path (dbg 8192), RGBA (alpha bicubic), TTA, BGR order; widths that are not multiples of 4 (unaligned source rows),
+    images smaller than the halo (every column reflected), tiles of 1 / 31 / 33 pixels, 200-pixel tiles."""
+    t = R.RealSR(0, tta_mode=True)
+    t.load(*paths)
+    cases = [(50, 43, 3, 32), (37, 41, 4, 32), (5, 3, 3, 32), (1, 1, 4, 32), (33, 65, 3, 31), (131, 67, 4, 33), (301, 215, 3, 200), (97, 203, 4, 200)]
+    try:
+        for eng, extra in ((sr, 8192), (sr, 0), (t, 0)):
+            for (w, h, c, T) in cases:
+                if eng is t and (c == 4 or T == 200):
+                    continue
+                eng.tilesize = T
+                img = synth.make_image(300 + w, w, h, c)
+                for bgr in (0, 1):
+                    eng.set_option("bgr", bgr)
+                    try:
+                        eng.set_option("dbg", extra | 65536)
+                        new = eng.process(img)
+                        eng.set_option("dbg", extra | 32768)
+                        old = eng.process(img)
+                        eng.set_option("dbg", extra)
+                        dflt = eng.process(img)
+                    finally:
+                        eng.set_option("dbg", 0)
+                        eng.set_option("bgr", 0)
+                    assert (new == old).all(), (w, h, c, T, bgr, eng.tta_mode, int((new != old).sum()))
+                    assert (dflt == old).all(), (w, h, c, T, bgr, eng.tta_mode)
+        t.tilesize = 200
+        img = synth.make_image(77, 260, 230)  # all four tile shapes, transposed-shape slots
+        new = t.process(img)                  # default under TTA: the LDS-staged gather
+        t.set_option("dbg", 32768)
+        assert (t.process(img) == new).all()
+        t.set_option("dbg", 65536)
+        assert (t.process(img) == new).all()
+    finally:
+        t.close()
+        sr.set_option("dbg", 0)
 
 
 def test_dead_output_elimination_at_other_prepaddings(sr):

@@ -505,8 +505,8 @@ def main():
                 # the same frame executes fewer FLOPs than the algorithmic count: -13.9 % of the 4x-level blocks (dead-output elimination),
                 # +2.6 % at the LR level (16 x 32 block quantisation in x; PMC SQ_INSTS_VALU_MFMA_MOPS_F16, profiles/r03_pmc_counters.txt)
                 "whole_path_frac_of_peak_executed": round(ppx * (EXECUTED_FLOP_PER_PADDED_LR_PX) * world * args.steps / dt / 1e12 / PEAK_F16_TFLOPS / world, 4),
-                "frac_of_peak_caveat": "one binary measured 88.7-93.9 ms on five boards of round 3 (38.9-41.1 % whole path): the boards differ in the clock their "
-                                       "power management grants under the 1,400 W cap; a single run is one board's number, not a floor",
+                "frac_of_peak_caveat": "one binary measured 88.7-93.9 ms on five boards of round 3 and 89.0-93.0 ms on eight of round 4 (38.9-41.1 % whole path): the boards "
+                                       "differ in the clock their power management grants under the 1,400 W cap; a single run is one board's number, not a floor",
                 "checksum": checksum,
             },
         }
@@ -562,8 +562,8 @@ def main():
                 "post_ms_per_step": round(prof["post_ms"] / args.steps, 4),
                 "post_GBps": round(prof["post_bytes"] / max(prof["post_ms"], 1e-9) / 1e6, 1),
                 "timing": "hipEvents on the launch stream around every kernel of the timed steps (rank 0), inside the timed region",
-                "note": "the board sits at its 1400 W cap during this workload (profiles/r03_power_clock.txt: 1400 W mean, sclk 1.60 GHz of 2.4 over the timed region): "
-                        "at that clock the MFMA peak is ~1.67 PFLOP/s",
+                "note": "the board sits at its 1400 W cap during this workload (profiles/r04_power_clock.txt: 1400 W mean, sclk ~1.65 GHz of 2.4 over the timed region): "
+                        "at that clock the MFMA peak is ~1.7 PFLOP/s; fed entirely from the L2 the same kernels reach 45-51 % of 2.5 PF (profiles/r04_l2_bound.txt)",
             }
             try:
                 g = board_gemm_ceiling(dev)

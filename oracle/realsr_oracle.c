@@ -491,52 +491,65 @@ ORC_API void orc_conv3x3(const float* in, int cin, int h, int w, const float* we
         for (int y = 0; y < h; y++)
             memcpy(pad + ((size_t)c * ph + y + 1) * pw + 1, in + ((size_t)c * h + y) * w, sizeof(float) * (size_t)w);
 
+    /* Register blocking for speed only (the test suite spends most of its time here): OB output channels x XB pixels of one row
+       accumulate over all input channels in a small local array, so every loaded input value feeds OB outputs.  Per output the
+       operations and their order are the ones of the plain triple loop: bias, then for ic ascending the three tap rows. */
+    enum { OB = 4, XB = 64 };
     const int RB = 8; /* row block */
-    const int nrb = (h + RB - 1) / RB;
+    const int nrb = (h + RB - 1) / RB, nob = (cout + OB - 1) / OB;
 #pragma omp parallel for collapse(2) schedule(dynamic)
-    for (int oc = 0; oc < cout; oc++)
+    for (int ob = 0; ob < nob; ob++)
         for (int rb = 0; rb < nrb; rb++)
         {
+            const int oc0 = ob * OB, noc = (oc0 + OB <= cout) ? OB : cout - oc0;
             const int y0 = rb * RB, y1 = (y0 + RB < h) ? y0 + RB : h;
-            float* o = out + (size_t)oc * h * w;
-            const float b = bias ? bias[oc] : 0.f;
             for (int y = y0; y < y1; y++)
-                for (int x = 0; x < w; x++) o[(size_t)y * w + x] = b;
-            for (int ic = 0; ic < cin; ic++)
-            {
-                const float* k = weight + ((size_t)oc * cin + ic) * 9;
-                const float k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3], k4 = k[4], k5 = k[5], k6 = k[6], k7 = k[7], k8 = k[8];
-                const float* ip = pad + (size_t)ic * ph * pw;
-                for (int y = y0; y < y1; y++)
+                for (int x0 = 0; x0 < w; x0 += XB)
                 {
-                    const float* r0 = ip + (size_t)y * pw;
-                    const float* r1 = r0 + pw;
-                    const float* r2 = r1 + pw;
-                    float* orow = o + (size_t)y * w;
-                    for (int x = 0; x < w; x++)
+                    const int n = (x0 + XB <= w) ? XB : w - x0;
+                    float acc[OB][XB];
+                    for (int j = 0; j < OB; j++)
                     {
-                        float s = orow[x];
-                        s += k0 * r0[x] + k1 * r0[x + 1] + k2 * r0[x + 2];
-                        s += k3 * r1[x] + k4 * r1[x + 1] + k5 * r1[x + 2];
-                        s += k6 * r2[x] + k7 * r2[x + 1] + k8 * r2[x + 2];
-                        orow[x] = s;
+                        const float b = (bias && j < noc) ? bias[oc0 + j] : 0.f;
+                        for (int x = 0; x < n; x++) acc[j][x] = b;
+                    }
+                    for (int ic = 0; ic < cin; ic++)
+                    {
+                        const float* r0 = pad + ((size_t)ic * ph + y) * pw + x0;
+                        const float* r1 = r0 + pw;
+                        const float* r2 = r1 + pw;
+                        float k[OB][9];
+                        for (int j = 0; j < OB; j++)
+                            for (int t = 0; t < 9; t++) k[j][t] = j < noc ? weight[((size_t)(oc0 + j) * cin + ic) * 9 + t] : 0.f;
+                        for (int x = 0; x < n; x++)
+                        {
+                            const float a0 = r0[x], a1 = r0[x + 1], a2 = r0[x + 2];
+                            const float a3 = r1[x], a4 = r1[x + 1], a5 = r1[x + 2];
+                            const float a6 = r2[x], a7 = r2[x + 1], a8 = r2[x + 2];
+#define ORC_ACC(J)                                                                     \
+    {                                                                                  \
+        float s = acc[J][x];                                                           \
+        s += k[J][0] * a0 + k[J][1] * a1 + k[J][2] * a2;                               \
+        s += k[J][3] * a3 + k[J][4] * a4 + k[J][5] * a5;                               \
+        s += k[J][6] * a6 + k[J][7] * a7 + k[J][8] * a8;                               \
+        acc[J][x] = s;                                                                 \
+    }
+                            ORC_ACC(0) ORC_ACC(1) ORC_ACC(2) ORC_ACC(3)
+#undef ORC_ACC
+                        }
+                    }
+                    for (int j = 0; j < noc; j++)
+                    {
+                        float* orow = out + ((size_t)(oc0 + j) * h + y) * w + x0;
+                        for (int x = 0; x < n; x++)
+                        {
+                            float v = acc[j][x];
+                            if (act_type == 2) v = v < 0.f ? v * slope : v; /* leakyrelu */
+                            else if (act_type == 1) v = v < 0.f ? 0.f : v;
+                            orow[x] = v;
+                        }
                     }
                 }
-            }
-            if (act_type == 2) /* leakyrelu */
-                for (int y = y0; y < y1; y++)
-                    for (int x = 0; x < w; x++)
-                    {
-                        float v = o[(size_t)y * w + x];
-                        o[(size_t)y * w + x] = v < 0.f ? v * slope : v;
-                    }
-            else if (act_type == 1)
-                for (int y = y0; y < y1; y++)
-                    for (int x = 0; x < w; x++)
-                    {
-                        float v = o[(size_t)y * w + x];
-                        o[(size_t)y * w + x] = v < 0.f ? 0.f : v;
-                    }
         }
     free(pad);
 }

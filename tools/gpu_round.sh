@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box session: bench JSON, rocprofv3 kernel-trace stats, PMC passes (HBM traffic + MFMA / LDS / clock counters).
-# Usage: tools/gpu_round.sh <tag>     -> gpurun_out/<tag>/{bench.json,power_clock.txt,kernel_stats.csv,pmc_traffic.txt,pmc_counters.txt}
+# Usage: tools/gpu_round.sh <tag>  (default r04)     -> gpurun_out/<tag>/{bench.json,power_clock.txt,kernel_stats.csv,pmc_traffic.txt,pmc_counters.txt}
 # Copy the summaries you want judged into profiles/ (tracked).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

@@ -30,6 +30,7 @@
 // LDS-DMA (global_load_lds_dwordx4).  Work-item descriptors are fetched with SCALAR loads (they neither touch the
 // loaders' vmcnt bookkeeping nor need LDS), so a launch never has to be split.
 #include "kernels.h"
+#include "model.h" // row_cout(): the order of the output channels in the rows of a weight image
 
 namespace rsr {
 
@@ -317,14 +318,12 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     };
     load_bias();
 
-    // transpose scratch of this wave: per n-tile two 16-channel plane rows of 32 px x 32 B; write side (accumulator
-    // layout) lane (px, hi) owns 8 B at px*32 + ((q&1) ^ f(px))*16 + hi*8 of plane q>>1, f(px) = (px>>2)&1;
-    // read side lane (px' = lane>>1, k = lane&1) takes 16 B = channels k*8..+7.
-    char* const scr = smem + kScrOff + wave * (NTW * 2048);
-    const int scr_w = l32 * 32 + hi * 8, scr_wx = ((l32 >> 2) & 1) << 4;
-    const int rpx = lane >> 1, rk = lane & 1;
-    const int scr_r = rpx * 32 + ((rk ^ ((rpx >> 2) & 1)) << 4);
-
+    // Epilogue lane map.  The weight images carry their rows in the order row_cout() (model.h): register q*4+e of lane (px, hi)
+    // = row q*8 + hi*4 + e of the MFMA result = output channel (q>>1)*16 + hi*8 + (q&1)*4 + e, i.e. registers 0..7 are the 8
+    // consecutive channels hi*8.. of the n-tile's first plane, 8..15 those of its second: converted to fp16 they are the 16
+    // bytes at pixel*32 + hi*16 of the plane row -- one buffer_store_b128 per plane, no transpose through LDS (rounds 1-3 went
+    // accumulator -> ds_write_b64 x4 -> ds_read_b128 x2 -> store per row; the 64 lanes of a store cover the same 1 KiB either
+    // way, and the (pixel, half) lane order stores as fast as the pixel-pair order: tools/ubench/store_pattern.hip).
     const float slope = a.lrelu ? 0.2f : 1.f;
     const bool idt = (EPI == 2) && a.res1_in_acc; // a fetched first residual arrives as res2 with s2 = 1 (launch_conv_flow)
     const bool has2 = (EPI == 2) && a.res2_kind == 1;
@@ -349,8 +348,8 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         OutDesc o;
         o.base = const_cast<char*>(plane_ptr(a.out16, it.slot, ntw0 * 2));
         o.live = (live && !(a.dbg & 4)) ? 1 : 0;
-        const int x = it.x0 + rpx;
-        o.voff = x < it.W ? x * kFPx + rk * 16 : int(0x80000000u);
+        const int x = it.x0 + l32;
+        o.voff = x < it.W ? x * kFPx + hi * 16 : int(0x80000000u);
         o.y0 = it.y0 + wrow * 4;
         o.H = it.H;
         o.W = it.W;
@@ -358,29 +357,28 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         o.slot = it.slot;
         return o;
     };
-    // one finished row (32 px x 32 cout of n-tile n): scale / LeakyReLU, fp16, transpose-write into the scratch
-    auto row_to_lds = [&](const f32x16& acc, int n) {
-        char* wr = scr + n * 2048 + scr_w;
+    // one finished row (32 px x 32 cout of an n-tile): scale / LeakyReLU, fp16; tq[p] = this lane's 16 bytes of output plane p
+    auto row_pack = [&](const f32x16& acc, u32x4 (&tq)[2]) {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int p = 0; p < 2; p++)
         {
-            half4 o;
+            half8 o;
 #pragma unroll
-            for (int e = 0; e < 4; e++)
+            for (int e = 0; e < 8; e++)
             {
-                float v = acc[q * 4 + e];
-                if (EPI == 2) v = v * a.s1;
+                float v = acc[p * 8 + e];
+                if (EPI == 2)
+                {
+                    v = v * a.s1;
+                    asm volatile("" : "+v"(v)); // see row_emit
+                }
                 else v = __builtin_amdgcn_fmed3f(v, v * slope, pinf0); // = max(v, slope*v), one instruction
                 o[e] = (_Float16)v;
             }
-            *reinterpret_cast<half4_scr*>(wr + (q >> 1) * 1024 + (((q & 1) << 4) ^ scr_wx)) = o;
+            tq[p] = __builtin_bit_cast(u32x4, o);
         }
     };
-    auto row_from_lds = [&](u32x4 (&tq)[2], int n) {
-#pragma unroll
-        for (int p = 0; p < 2; p++) tq[p] = *reinterpret_cast<const u32x4_scr*>(scr + n * 2048 + p * 1024 + scr_r);
-    };
-    // residual stage in the transposed domain (lane = 8 consecutive channels of one pixel): v = v*s2 + r2
+    // residual stage (a lane holds 8 consecutive channels of one pixel, like the residual's plane rows): v = v*s2 + r2
     // The second residual (the RRDB input, every third conv5) is fetched ahead of its use when the registers allow it (one
     // n-tile per wave) -- rows 0-1 one half-stage before the epilogue, rows 2-3 into the same registers once the
     // epilogue is through with rows 0-1: four dependent HBM round trips per block otherwise.
@@ -405,20 +403,6 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             for (int n = 0; n < NTW; n++) res2_row(r2q[PRE2 ? rr : 0][n], o, row0 + rr, n);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto row_residual = [&](u32x4 (&tq)[2], const OutDesc& o, int rr, int n) {
-        if (!has2) return;
-        u32x4 r2x[2];
-        if (!PRE2) res2_row(r2x, o, rr, n);
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-        {
-            const half8 r2 = __builtin_bit_cast(half8, PRE2 ? r2q[PRE2 ? (rr & 1) : 0][n][p] : r2x[p]);
-            half8 v = __builtin_bit_cast(half8, tq[p]);
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (_Float16)((float)v[e] * a.s2 + (float)r2[e]);
-            tq[p] = __builtin_bit_cast(u32x4, v);
-        }
-    };
     // 1 KiB per store instruction: 32 pixels x 32 B of one 16-channel plane row; rows / columns outside the image are
     // dropped by the buffer range check (null resource / out-of-range offset), so the epilogue is branch-free
     auto row_store = [&](const u32x4 (&tq)[2], const OutDesc& o, int rr, int n) {
@@ -433,6 +417,44 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
         for (int p = 0; p < 2; p++)
             __builtin_amdgcn_raw_buffer_store_b128(tq[p], rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride), 0, 0);
+    };
+    // the inline epilogue of one row: plane by plane (pack -> residual -> store), so that only one 16-byte value is live at a time
+    // (the 168-VGPR kernels have no room for a whole packed row next to the prefetched residual)
+    auto row_emit = [&](const f32x16& acc, const OutDesc& o, int rr, int n) {
+        const int y = o.y0 + rr;
+        char* ub = uniform_ptr(o.base);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
+        const unsigned pstride = unsigned(a.out16.plane_stride);
+        u32x4 r2x[2];
+        if (EPI == 2 && has2 && !PRE2) res2_row(r2x, o, rr, n);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+        {
+            half8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+            {
+                float f = acc[p * 8 + e];
+                if (EPI == 2)
+                {
+                    f = f * a.s1;
+                    // the product is rounded to fp32 BEFORE it becomes an fp16 (as in rounds 1-3): left visible, the compiler fuses
+                    // multiply and conversion into one v_fma_mix with a single rounding in some instantiations and not in others
+                    // (1 ulp on 1e-4 of the values, seen as a changed frame checksum) -- the kernel variants must agree bit for bit
+                    asm volatile("" : "+v"(f));
+                }
+                else f = __builtin_amdgcn_fmed3f(f, f * slope, pinf0);
+                v[e] = (_Float16)f;
+            }
+            if (EPI == 2 && has2)
+            {
+                const half8 r2 = __builtin_bit_cast(half8, PRE2 ? r2q[PRE2 ? (rr & 1) : 0][n][p] : r2x[p]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = (_Float16)((float)v[e] * a.s2 + (float)r2[e]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride), 0, 0);
+            __builtin_amdgcn_sched_barrier(0); // one plane at a time: interleaved, the two planes' temporaries do not fit the 168-VGPR kernels
+        }
     };
     // conv_last (EPI 0): channels 0..2 of n-tile 0 -> planar fp16 [3][H][W] (the reference's `output` blob, consumed by
     // postproc_tiles), or -- non-TTA RGB -- straight into the uint8 image: realsr_postproc.comp:62-83 on the value rounded to
@@ -631,7 +653,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         {                                                                                                            \
             half8 idf;                                                                                               \
             _Pragma("unroll") for (int e = 0; e < 8; e++) idf[e] =                                                   \
-                ((ck & 1) * 16 + hi * 8 + e == l32) ? (_Float16)a.res1_coef : (_Float16)0.f;                         \
+                ((ck & 1) * 16 + hi * 8 + e == row_cout(l32)) ? (_Float16)a.res1_coef : (_Float16)0.f;               \
             const char* cb_ = xbase(sP, 1);                                                                          \
             _Pragma("unroll") for (int rr = 0; rr < 4; rr++)                                                         \
             {                                                                                                        \
@@ -897,15 +919,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 {
                     if (rr == 3) refill();
 #pragma unroll
-                    for (int n = 0; n < NTW; n++) row_to_lds(accA[rr][n], n);
-#pragma unroll
-                    for (int n = 0; n < NTW; n++)
-                    {
-                        u32x4 tq[2];
-                        row_from_lds(tq, n);
-                        if (EPI == 2) row_residual(tq, o, rr, n);
-                        row_store(tq, o, rr, n);
-                    }
+                    for (int n = 0; n < NTW; n++) row_emit(accA[rr][n], o, rr, n);
                     if (EPI == 2 && rr == 1) res2_prefetch(it, 2);
                 }
             }
@@ -926,7 +940,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         // drains its uninitialised partner set into a null resource.
         OutDesc od = make_out(it, false);
         u32x4 tq[2];
-        half2v pk[4][2];
+        half2v pk[2][4][2]; // value pairs of the row being converted, two rows in flight (a row's stores read set r & 1)
         float pinf = __builtin_inff();
         asm volatile("" : "+s"(pinf)); // opaque: med3(v, s*v, +inf) stays ONE instruction (a literal folds to maxnum + canonicalize)
         auto row_store1 = [&](const u32x4& v, const OutDesc& o, int rr, int p) {
@@ -946,8 +960,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         {                                                                                                            \
             _Pragma("unroll") for (int rr = 0; rr < 4; rr++)                                                         \
             {                                                                                                        \
-                row_to_lds(RSR_OLD[rr][0], 0);                                                                       \
-                row_from_lds(tq, 0);                                                                                 \
+                row_pack(RSR_OLD[rr][0], tq);                                                                        \
                 row_store(tq, od, rr, 0);                                                                            \
             }                                                                                                        \
         }                                                                                                            \
@@ -960,13 +973,13 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     else                                                                                                             \
     {                                                                                                                \
         ck = 0;                                                                                                      \
-        RSR_HALF(ACC, Wa, Wb, true, RSR_HK_S0, 0, RSR_HK_S1, 0, RSR_HK_S2, 0)                                        \
+        RSR_HALF(ACC, Wa, Wb, true, RSR_HK_S0, RSR_PIN_S0, RSR_HK_S1, RSR_PIN_S1, RSR_HK_S2, RSR_PIN_S2)             \
         ck = 1;                                                                                                      \
-        RSR_HALF(ACC, Wb, Wa, false, RSR_HK_S3, 0, RSR_HK_S4, 0, RSR_HK_S5, 0)                                       \
+        RSR_HALF(ACC, Wb, Wa, false, RSR_HK_S3, RSR_PIN_S3, RSR_HK_S4, RSR_PIN_S4, RSR_HK_S5, RSR_PIN_S5)            \
         ck = 2;                                                                                                      \
-        RSR_HALF(ACC, Wa, Wb, false, RSR_HK_S6, 0, RSR_HK_S7, 0, RSR_HK_S8, 0)                                       \
+        RSR_HALF(ACC, Wa, Wb, false, RSR_HK_S6, RSR_PIN_S6, RSR_HK_S7, RSR_PIN_S7, RSR_HK_S8, RSR_PIN_S8)            \
         ck = 3;                                                                                                      \
-        RSR_HALF(ACC, Wb, Wa, false, RSR_HK_S9, 0, RSR_NOHK, 1, RSR_NOHK, 1)                                         \
+        RSR_HALF(ACC, Wb, Wa, false, RSR_HK_S9, RSR_PIN_S9, RSR_HK_S10, RSR_PIN_S10, RSR_HK_S11, RSR_PIN_S11)        \
         for (int cp = 4; cp < nst; cp += 2)                                                                          \
         {                                                                                                            \
             ck = cp;                                                                                                 \
@@ -998,8 +1011,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
             for (int rr = 0; rr < 4; rr++)
             {
-                row_to_lds(accA[rr][0], 0);
-                row_from_lds(tq, 0);
+                row_pack(accA[rr][0], tq);
                 row_store(tq, od, rr, 0);
             }
         }
@@ -1008,8 +1020,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
             for (int rr = 0; rr < 4; rr++)
             {
-                row_to_lds(accB[rr][0], 0);
-                row_from_lds(tq, 0);
+                row_pack(accB[rr][0], tq);
                 row_store(tq, od, rr, 0);
             }
         }

@@ -487,9 +487,11 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
             return f32_to_f16(v);
         };
         const int rows = 9 * nt * 32;
+        // image row n (and bias entry n) carries output channel co(n): see row_cout() in model.h
+        auto co = [](int n) { return (n & ~31) + row_cout(n & 31); };
         P.b_off = off;
         float* B = reinterpret_cast<float*>(base + off);
-        for (int n = 0; n < c.cout; n++) B[n] = c.bias[size_t(n)];
+        for (int n = 0; n < nt * 32; n++) B[n] = co(n) < c.cout ? c.bias[size_t(co(n))] : 0.f;
         off = align256(off + size_t(nt) * 32 * 4);
         P.w16_off = off;
         uint16_t* W16 = reinterpret_cast<uint16_t*>(base + off);
@@ -501,7 +503,7 @@ int pack_model(const Model& m, void* dst, size_t cap, std::string& err)
                     for (int slot = 0; slot < 2; slot++)
                     {
                         const int pslot = slot ^ ((n >> 3) & 1);
-                        for (int e = 0; e < 8; e++) R[pslot * 8 + e] = wt(n, pl * 16 + slot * 8 + e, tap);
+                        for (int e = 0; e < 8; e++) R[pslot * 8 + e] = wt(co(n), pl * 16 + slot * 8 + e, tap);
                     }
                 }
         off = align256(off + size_t(2 * np) * rows * 32);

@@ -80,7 +80,14 @@ struct PackedConv
     uint64_t w16_off;       // 16-channel-plane images
     uint64_t aux_off;       // convs with <= 4 output channels (conv_last): [plane][dx 0..2][row = dy*8 + cout][16 cin], 3 KB per plane; else 0
 };
-constexpr uint32_t kPackedVersion = 5;
+constexpr uint32_t kPackedVersion = 6;
+
+// Which output channel sits in row i (0..31) of a 32-row weight image (and of the bias block): the v_mfma_f32_32x32x16_f16 result
+// leaves row q*8 + hi*4 + e in register q*4 + e of lane (pixel, hi).  With the rows ordered like this a lane's registers 0..7 are
+// the 8 CONSECUTIVE channels hi*8 .. hi*8+7 of the first output plane and 8..15 those of the second: 16 bytes of fp16 that go to
+// memory as they are -- no transpose through LDS in the epilogue (conv_flow.hip).  A bijection on 0..31 (swaps 4-7 <-> 8-11 and
+// 20-23 <-> 24-27); rows 0..3 stay channels 0..3 (conv_last's three outputs).
+constexpr int row_cout(int i) { return ((i >> 4) & 1) * 16 + ((i >> 2) & 1) * 8 + ((i >> 3) & 1) * 4 + (i & 3); }
 constexpr uint32_t kPackedMagic = 0x50525352u; // "RSRP"
 
 size_t packed_size(const Model& m);

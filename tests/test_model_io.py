@@ -100,7 +100,7 @@ def test_packed_blob_layout(model_dir, weights):
     assert rec.itemsize == 48
     specs = synth.conv_specs()
     magic, version, nconv, flags = np.frombuffer(bl[:16], np.uint32)
-    assert magic == 0x50525352 and version == 5 and nconv == 351 and flags == 0
+    assert magic == 0x50525352 and version == 6 and nconv == 351 and flags == 0
     assert int(np.frombuffer(bl[16:24], np.uint64)[0]) == bl.size
     table = np.frombuffer(bl[24:24 + 351 * 48], rec)
     for i in (0, 1, 4, 5, 346, 349, 350):
@@ -113,18 +113,25 @@ def test_packed_blob_layout(model_dir, weights):
         W, b = weights[i]
         Wp = np.zeros((nt * 32, np_ * 32, 3, 3), np.float32)
         Wp[:cout, :cin] = W
-        # 16-channel-plane images: [plane][tap][cout][2 slots of 8], slots swapped when (cout >> 3) & 1
+        # 16-channel-plane images: [plane][tap][row][2 slots of 8], slots swapped when (row >> 3) & 1; row n of a 32-row tile carries
+        # output channel row_cout(n) (model.h: the order in which the MFMA result registers are consecutive channels)
+        def row_cout(n):
+            i = n & 31
+            return (n & ~31) + ((i >> 4) & 1) * 16 + ((i >> 2) & 1) * 8 + ((i >> 3) & 1) * 4 + (i & 3)
+        assert sorted(row_cout(n) for n in range(64)) == list(range(64)) and [row_cout(n) for n in (0, 3, 4, 8, 12, 20, 24, 31)] == [0, 3, 8, 4, 12, 24, 20, 31]
         img16 = np.frombuffer(bl[int(t["w16_off"]):int(t["w16_off"]) + 2 * np_ * rows * 32], np.float16).reshape(2 * np_, rows, 2, 8)
         for pl in range(2 * np_):
-            for row in (0, 5, 9, 31, 40, rows - 1):
+            for row in (0, 5, 9, 21, 31, 40, rows - 1):
                 tap, n = divmod(row, nt * 32)
                 swz = (n >> 3) & 1
                 for slot in range(2):
                     got = img16[pl, row, slot ^ swz].astype(np.float32)
-                    want = Wp[n, pl * 16 + slot * 8: pl * 16 + slot * 8 + 8, tap // 3, tap % 3]
+                    want = Wp[row_cout(n), pl * 16 + slot * 8: pl * 16 + slot * 8 + 8, tap // 3, tap % 3]
                     assert (got == want).all(), (i, pl, row, slot)
         bias = np.frombuffer(bl[int(t["b_off"]):int(t["b_off"]) + nt * 32 * 4], np.float32)
-        assert (bias[:cout] == b).all() and (bias[cout:] == 0).all()
+        bp_ = np.zeros(nt * 32, np.float32)
+        bp_[:cout] = b
+        assert (bias == bp_[[row_cout(n) for n in range(nt * 32)]]).all()
         # conv_last's aux image, (dy, cout) in the MFMA's M dimension: [plane][dx][row = dy*8 + c][2 slots of 8], other rows zero
         if cout <= 4:
             aux = np.frombuffer(bl[int(t["aux_off"]):int(t["aux_off"]) + 2 * np_ * 3 * 32 * 32], np.float16).reshape(2 * np_, 3, 32, 2, 8)

@@ -62,7 +62,9 @@ struct FlowCfg
     static constexpr int WR = 3;               // weight ring depth
     static constexpr int WB = NT * 9 * 32 * 32; // bytes of one weight image [9 taps][NT*32 cout][16 cin]
     static constexpr int WPIECES = NT * 9;
-    static constexpr int SCR = 4 * NT * 2048;  // transpose scratch: one 32-px row x 32 cout per (wave, n-tile)
+    static constexpr int SCR = 4 * NT * 2048;  // rounds 1-3: the epilogue's transpose scratch.  Unused since round 4 (the epilogue no longer goes
+                                               // through LDS) and kept reserved: handing it to the patch ring (cin 96 / 128: one slot more, conv5: 5
+                                               // instead of 4) measured +0.2 ... +0.4 % frame time (profiles/r04_ab_epilogue.txt)
     static constexpr int W_OFF = PR * kFPatch;
     static constexpr int SCR_OFF = W_OFF + WR * WB;
     static constexpr int BIAS_OFF = SCR_OFF + SCR;

@@ -18,8 +18,14 @@
 //     middle of the MFMA stream, after the wave's last LDS read of the half-stage ("early barrier": the slot is
 //     handed back to the loaders a third of a half-stage before its MFMAs finish).
 //   * epilogue: bias enters as the C operand of the block's first MFMAs; finished rows go fp32 -> (scale / LeakyReLU)
-//     -> fp16 -> private LDS scratch (transpose) -> 1-KiB buffer stores.  With 32 output channels (4 MFMA waves, 256
-//     VGPRs) the accumulators are double-buffered and block r is drained row by row underneath block r+1's MFMAs.
+//     -> fp16 -> 1-KiB buffer stores (rounds 1-3: through a private LDS transpose scratch; round 4: straight from the
+//     registers, see below).  With 32 output channels (4 MFMA waves, 256 VGPRs) the accumulators are double-buffered and
+//     block r is drained row by row underneath block r+1's MFMAs.
+//
+// Round 4: NO TRANSPOSE in the epilogue.  The rows of the weight images are ordered (model.h row_cout) so that the registers of
+// an MFMA result are runs of 8 consecutive output channels: a lane's 16 bytes of a plane row go to memory as they are (one
+// buffer_store_b128 per plane), the 4 ds_write_b64 + 2 ds_read_b128 per row and their waits are gone, and the deferred drain
+// (40 pieces instead of 60) rides behind every THIRD MFMA cell: -1.3 % frame time (profiles/r04_ab_epilogue.txt).
 //
 // Round 3: weight images LDS-RESIDENT for the whole launch where they fit (WRES: every conv but the 192 -> 64
 // ones), MFMA waves SKIP blocks whose four rows lie below the tile or inside the frame of output pixels nothing kept depends on
@@ -40,10 +46,6 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-// The transpose scratch is written as half4 and read back as u32x4: without may_alias, type-based alias analysis lets
-// the compiler move row k+1's writes above row k's read-back (seen on hardware as a run-to-run varying corruption).
-typedef half4 __attribute__((may_alias)) half4_scr;
-typedef u32x4 __attribute__((may_alias)) u32x4_scr;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 __attribute__((may_alias)) f32x4_lds;
 
@@ -933,13 +935,13 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     else
     {
         // ---- deferred epilogue (32 output channels, 4 MFMA waves): block r accumulates into one accumulator set while
-        // the other set, holding block r-1, is drained during block r's first ten steps.  The work is cut into 60 pieces
-        // of <= 5 instructions that ride behind every second MFMA cell (fenced in place; generated by
+        // the other set, holding block r-1, is drained during block r's first ten steps.  The work is cut into 40 pieces
+        // of <= 5 instructions that ride behind every THIRD MFMA cell (fenced in place; generated by
         // tools/gen_flow_hooks.py): per row eight conversions of a value pair (LeakyReLU = med3(v, slope*v, +inf), fp16
-        // pack), four ds_write_b64 into the transpose scratch, one read-back (2 ds_read_b128) and, three pieces later, the
-        // two 1-KiB stores.  ~2.5 VALU instructions per 32-cycle MFMA slot: the matrix pipe does not notice (at one piece per
-        // cell -- the drain squeezed into five steps -- a block's first two half-stages ran 30-50 % long).  The first block
-        // drains its uninitialised partner set into a null resource.
+        // pack) and the two 1-KiB stores of the row's planes, straight from the packed pairs (double-buffered by row).
+        // Measured: a piece behind every cell 89.9 ms per C2 frame, every second 89.4-89.6, every third 88.9, 3.5 no better;
+        // the round-3 drain (60 pieces incl. the LDS transpose, every second cell) 90.1.  The first block drains its
+        // uninitialised partner set into a null resource.
         OutDesc od = make_out(it, false);
         u32x4 tq[2];
         half2v pk[2][4][2]; // value pairs of the row being converted, two rows in flight (a row's stores read set r & 1)

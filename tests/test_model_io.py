@@ -226,3 +226,30 @@ def test_real_model_harness_skips_without_a_blob_and_runs_host_checks(model_dir,
     assert rep["encoding_by_size"] == rep["encoding_by_parser"] == "fp16-tagged" and rep["bin_bytes"] == 33424520
     assert rep["walk_vs_oracle_max"] < 1e-4 and len(rep["activation_peaks"]) == 1 + 69 + 4
     assert 1.0 < max(v for _, v in rep["activation_peaks"]) < 65504
+
+
+def test_flow_hook_generator_schedules_every_piece_once(tmp_path):
+    """tools/gen_flow_hooks.py (run by the csrc Makefile): the deferred drain of one block = 4 rows x (8 pair conversions + 2 plane
+    stores) = 40 pieces, each behind exactly one MFMA cell, a row's stores behind its conversions, every third cell by default;
+    steps without a piece get an empty hook and the plain step schedule (RSR_PIN_S<step> 1)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("RSR_HOOK_STRIDE", None)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_flow_hooks.py"), str(tmp_path)], env=env, stdout=subprocess.DEVNULL)
+    inc = (tmp_path / "conv_flow_hooks.inc").read_text().splitlines()
+    cells = {}
+    for ln in inc:
+        m = re.match(r"#define RSR_HK_S(\d+)_(\d+) (.*)", ln)
+        if m and "pk[" in m.group(3):
+            cells[12 * int(m.group(1)) + int(m.group(2))] = m.group(3)
+    order = sorted(cells)
+    assert len(order) == 40 and order[0] == 1 and all(b - a == 3 for a, b in zip(order, order[1:])) and order[-1] < 120
+    kinds = ["ST" if "row_store1" in cells[c] else "P" for c in order]
+    assert kinds == (["P"] * 8 + ["ST"] * 2) * 4
+    stores = [re.search(r"row_store1\(o_, od, (\d), (\d)\)", cells[c]).groups() for c in order if "row_store1" in cells[c]]
+    assert stores == [(str(r), str(p)) for r in range(4) for p in range(2)]
+    pins = dict(re.match(r"#define RSR_PIN_S(\d+) (\d)", ln).groups() for ln in inc if ln.startswith("#define RSR_PIN_S"))
+    assert [pins[str(s)] for s in range(12)] == ["0"] * 10 + ["1"] * 2
+    undef = (tmp_path / "conv_flow_hooks_undef.inc").read_text()
+    assert undef.count("#undef RSR_PIN_S") == 12

@@ -1,3 +1,7 @@
+"""Outputs of single convolutions of every kernel class (rsr_conv3x3 / rsr_conv3x3_res), of the network on one tile and of one
+end-to-end call, saved as .npz -- to compare two BUILDS of the library bit for bit:
+    RSR_LIB=<build A> python tools/conv_dump.py /tmp/a.npz;  RSR_LIB=<build B> python tools/conv_dump.py /tmp/b.npz
+(how round 4 found that the round-3 binary rounded acc*s1 once in some lanes -- a fused v_fma_mix -- and twice in others)."""
 import os, sys, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import realsr_ncnn_vulkan_amd as R

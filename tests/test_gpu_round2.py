@@ -543,6 +543,31 @@ def test_tile_rows_and_group_processing_equal_the_full_image(paths):
     b.close()
 
 
+def test_tile_ranges_under_tta_and_rgba(paths):
+    """Tile ranges with the other output paths: TTA contexts (8 slots per tile, the LDS-staged gather writing dword rows into a
+    device buffer that holds only the range's rows) and RGBA (alpha bicubic reads the INPUT image around the tile): every split
+    of the tile grid gives the bytes of one call."""
+    a, b = R.RealSR(0, tta_mode=True), R.RealSR(0, tta_mode=True)
+    for s in (a, b):
+        s.load(*paths)
+        s.tilesize = 32
+    try:
+        for img in (synth.make_image(64, 70, 110), synth.make_image(65, 45, 100, 4)):
+            want = a.process(img)
+            for parts in (2, 3, 7):
+                assert (R.process_group([(a, b)[i % 2] for i in range(parts)], img) == want).all(), (img.shape, parts)
+            out = np.zeros_like(want)
+            nt = -(-img.shape[1] // 32) * -(-img.shape[0] // 32)
+            cuts = [0, 1, nt // 2, nt - 1, nt]
+            for t0, t1 in zip(cuts, cuts[1:]):
+                if t1 > t0:
+                    b.process_tiles(img, out, t0, t1)
+            assert (out == want).all(), img.shape
+    finally:
+        a.close()
+        b.close()
+
+
 def test_create_group(paths, monkeypatch):
     """rsr_create_group: parse + pack once, one context per GPU (one GPU here: no collective needed); a duplicate id and a
     missing device are argument / device errors and leave no context behind."""

@@ -237,6 +237,8 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                       destinations (default 16); "copy_threads": CPU threads per staging copy of a pageable image
  *                       (default 4; 1 = the calling thread alone)
  *   "num_cu"            persistent grid size (profiling aid)
+ *   "test_repeat"       rsr_conv3x3 / rsr_conv3x3_res: the work items N times in ONE launch (an L2-resident workload; stat "last_test_us")
+ *   "ws_clamp_mb"       test hook: plant the workspace bound a failed allocation leaves behind (< 0 clears it; see rsr_get_stat)
  *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; -DRSR_FLOW_TRACE builds), -1 off
  *   "alternate_order"   1 [default]: every second conv walks its work items backwards (starts on the tiles the previous conv
  *                       touched last -> Infinity Cache hits); 0: always forwards

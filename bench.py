@@ -505,8 +505,8 @@ def main():
                 # the same frame executes fewer FLOPs than the algorithmic count: -13.9 % of the 4x-level blocks (dead-output elimination),
                 # +2.6 % at the LR level (16 x 32 block quantisation in x; PMC SQ_INSTS_VALU_MFMA_MOPS_F16, profiles/r03_pmc_counters.txt)
                 "whole_path_frac_of_peak_executed": round(ppx * (EXECUTED_FLOP_PER_PADDED_LR_PX) * world * args.steps / dt / 1e12 / PEAK_F16_TFLOPS / world, 4),
-                "frac_of_peak_caveat": "one binary measured 88.7-93.9 ms on five boards of round 3 and 89.0-93.0 ms on eight of round 4 (38.9-41.1 % whole path): the boards "
-                                       "differ in the clock their power management grants under the 1,400 W cap; a single run is one board's number, not a floor",
+                "frac_of_peak_caveat": "one binary measured 88.7-93.9 ms on five boards of round 3; the round-4 binary 87.5-93.8 ms on ten (38.9-41.7 % whole path): the boards "
+                                       "differ in the clock their power management grants under the 1,400 W cap (1,531-1,656 MHz seen); a single run is one board's number, not a floor",
                 "checksum": checksum,
             },
         }

@@ -239,12 +239,18 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "num_cu"            persistent grid size (profiling aid)
  *   "test_repeat"       rsr_conv3x3 / rsr_conv3x3_res: the work items N times in ONE launch (an L2-resident workload; stat "last_test_us")
  *   "ws_clamp_mb"       test hook: plant the workspace bound a failed allocation leaves behind (< 0 clears it; see rsr_get_stat)
+ *   "ws_fail_above_mb"  test hook: workspaces above this size fail to allocate, every time (a persistently fragmented device; < 0 off);
+ *                       stat "ws_failures" counts the refusals, "clamp_backoff" the calls between two attempts at the full size
  *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; -DRSR_FLOW_TRACE builds), -1 off
  *   "alternate_order"   1 [default]: every second conv walks its work items backwards (starts on the tiles the previous conv
  *                       touched last -> Infinity Cache hits); 0: always forwards
  *   "xcd_order"         1 [default]: the backward tables of "alternate_order" are reversed inside each XCD's share of the list, so an XCD
  *                       starts on the blocks IT wrote last (its own 4 MB L2); 0: the list is reversed as a whole
- *   "dbg"               ablation / A-B bits of ConvArgs::dbg, profiling only:
+ *   "fold"              1 [default]: a tile's last block column, when it is only 1..14 pixels wide, is computed by FOLDED work items
+ *                       (two block rows of that narrow column per 16 x 32 block: C3's 420-wide tiles 13.5 instead of 14 block
+ *                       columns); 0: one plain block column more.  Output bytes unchanged (kernels.h: kFoldBit)
+ *   "flow_flags" bit 4  size the patch ring as if the rounds 1-3 LDS transpose scratch were still reserved (A/B aid)
+ *   "dbg"               A-B bits of ConvArgs::dbg, profiling only (bits 1 / 4 / 64 / 128 act only in -DRSR_EXPERIMENT builds of conv_flow.hip):
  *                         1 skip LDS-DMA (64: weights only, 128: patches only), 4 skip epilogue stores, 32 MFMA waves do not skip rows
  *                         outside the tile / inside the unread frame, 8192 conv_last never writes the uint8 image itself, 16384 no split tail for early download,
  *                         32768 / 65536 force the one-thread-per-pixel / the LDS-staged pre and post kernels (default: chosen per launch) */

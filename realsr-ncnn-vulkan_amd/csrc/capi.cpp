@@ -358,6 +358,8 @@ int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value)
     else if (k == "plan_slots_per_batch") *value = e.plans.empty() ? 0.0 : double(e.plans.front().slots_per_batch);
     else if (k == "plans") *value = double(e.plans.size());
     else if (k == "ws_clamp_mb") *value = e.ws_clamp_bytes < 0 ? -1.0 : double(e.ws_clamp_bytes) / 1048576.0;
+    else if (k == "ws_failures") *value = double(e.ws_failures);
+    else if (k == "clamp_backoff") *value = double(e.clamp_backoff);
     else if (k == "workspace_mb")
     {
         double n = 0;
@@ -430,6 +432,8 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         ctx->e.xcd_order = value != 0; // plans are keyed by it
     else if (k == "alternate_order")
         ctx->e.alternate_order = value != 0;
+    else if (k == "fold")
+        ctx->e.fold_cols = value != 0; // plans are keyed by it
     else if (k == "dbg")
         ctx->e.dbg = int(value);
     else if (k == "test_repeat")
@@ -438,7 +442,14 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         ctx->e.test_repeat = int(value);
     }
     else if (k == "ws_clamp_mb") // test hook: what a failed workspace allocation leaves behind (enqueue_image's retry); < 0 clears it
+    {
         ctx->e.ws_clamp_bytes = value < 0 ? -1 : value * 1048576;
+        ctx->e.clamp_fail_avail = -1;
+        ctx->e.clamp_calls_left = 0;
+        ctx->e.clamp_backoff = 4;
+    }
+    else if (k == "ws_fail_above_mb") // test hook: workspaces above this size fail to allocate, persistently (< 0: off)
+        ctx->e.ws_fail_above_bytes = value < 0 ? -1 : value * 1048576;
     else if (k == "num_cu")
     {
         if (value < 8 || value > 1024) return ctx->e.fail(RSR_E_ARG, "num_cu out of range");

@@ -61,15 +61,14 @@ template <int NT>
 struct FlowCfg
 {
     static constexpr int PR = NT == 1 ? 6 : 4; // patch ring depth (half-stages)
-    static constexpr int WR = 3;               // weight ring depth
+#ifndef RSR_STREAM_WR
+#define RSR_STREAM_WR 3 // (4 = the LDS the transpose scratch used to hold as a fourth weight slot for conv5: A/B'ed in round 5, profiles/r05_ab_lds.txt)
+#endif
+    static constexpr int WR = RSR_STREAM_WR;   // weight ring depth of a streamed-weight launch
     static constexpr int WB = NT * 9 * 32 * 32; // bytes of one weight image [9 taps][NT*32 cout][16 cin]
     static constexpr int WPIECES = NT * 9;
-    static constexpr int SCR = 4 * NT * 2048;  // rounds 1-3: the epilogue's transpose scratch.  Unused since round 4 (the epilogue no longer goes
-                                               // through LDS) and kept reserved: handing it to the patch ring (cin 96 / 128: one slot more, conv5: 5
-                                               // instead of 4) measured +0.2 ... +0.4 % frame time (profiles/r04_ab_epilogue.txt)
     static constexpr int W_OFF = PR * kFPatch;
-    static constexpr int SCR_OFF = W_OFF + WR * WB;
-    static constexpr int BIAS_OFF = SCR_OFF + SCR;
+    static constexpr int BIAS_OFF = W_OFF + WR * WB; // (rounds 1-3 kept an 8 / 16 KB epilogue transpose scratch in front of the bias: gone, round 5)
     static constexpr int TOTAL = BIAS_OFF + NT * 128;
 };
 static_assert(FlowCfg<1>::TOTAL <= 160 * 1024 && FlowCfg<2>::TOTAL <= 160 * 1024, "LDS budget");
@@ -112,6 +111,20 @@ __device__ __forceinline__ char* uniform_ptr(const void* p)
 #define RSR_DSR 0x100
 #define RSR_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
+// Experiment scaffolding is compiled OUT of the product build.  -DRSR_EXPERIMENT (tools/build_variant.sh) brings back
+// the run-time ablation bits of ConvArgs::dbg -- 1 no LDS-DMA at all, 4 no epilogue stores, 64 no weight DMA, 128 no patch DMA (stale
+// LDS is multiplied: wrong results by construction) -- and admits the instrumented builds RSR_FLOW_LIFE / RSR_FLOW_TRACE (s_memtime
+// stamps) and RSR_EXP_THIN (the Winograd instruction-mix study of DESIGN.md 4.1).  dbg bit 32 ("compute the rows a wave would skip")
+// is a TEST hook with correct results and stays in every build.
+#ifdef RSR_EXPERIMENT
+#define RSR_ABL(bits) (a.dbg & (bits))
+#else
+#define RSR_ABL(bits) 0
+#if defined(RSR_FLOW_LIFE) || defined(RSR_FLOW_TRACE) || defined(RSR_EXP_THIN)
+#error "RSR_FLOW_LIFE / RSR_FLOW_TRACE / RSR_EXP_THIN are experiment builds: add -DRSR_EXPERIMENT"
+#endif
+#endif
+
 } // namespace
 
 // EPI: 0 generic (conv_last: planar fp16 [3][H][W] output)      1 v = act(acc)  -> fp16 planes      3 conv_last with (dy, cout) in M
@@ -147,7 +160,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     const int nst = a.n0 + a.n1; // half-stages per block (16-channel planes), even by construction (engine pads)
     // ring depths and LDS offsets: compile-time constants when the weights are streamed
     const int PR = WRES ? a.pr : C::PR, WR = WRES ? nst : C::WR;
-    const int kWOff = PR * kFPatch, kScrOff = kWOff + WR * (EPI == 3 ? a.wpieces * 1024 : WB), kBiasOff = kScrOff + C::SCR;
+    const int kWOff = PR * kFPatch, kBiasOff = kWOff + WR * (EPI == 3 ? a.wpieces * 1024 : WB);
 
     const int per = (a.nitems + 7) >> 3;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
@@ -195,12 +208,19 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         int uP = 0, uW = 0, sP = 0, sW = 0, ckP = 0, ckW = 0, rP = 0;
         WorkItem itP = load_item(a.items, first);
         unsigned srcoff[NP];
+        // A FOLDED block (WorkItem::x0 & kFoldBit; kernels.h): the last, <= 14 pixel wide column of a tile, two block rows at once.
+        // Patch columns 0..15 hold the halo'd strip of rows y0.. (left halo, <= 14 pixels, right halo), columns 16..31 the strip
+        // of rows y0 + 16..; the MFMA lanes read the patch exactly as they always do (pixel l32 + dx), so lanes 0..13 compute the
+        // first strip and lanes 16..29 the second -- only the loaders' source addresses and the epilogue's destinations differ.
         auto block_offsets = [&]() {
             const int H = itP.H, W = itP.W, Wi = UPS ? (W >> 1) : W;
+            const bool fold = (itP.x0 & kFoldBit) != 0;
+            const int bx0 = itP.x0 & (kFoldBit - 1);
 #pragma unroll
             for (int i = 0; i < NP; i++)
             {
-                const int gy = itP.y0 - 1 + pr[i], gx = itP.x0 - 1 + pc[i];
+                const int half = (fold && pc[i] >= 16) ? 16 : 0;
+                const int gy = itP.y0 - 1 + pr[i] + half, gx = bx0 - 1 + pc[i] - half;
                 const bool ok = pvalid[i] && gy >= 0 && gy < H && gx >= 0 && gx < W;
                 const int sy = UPS ? (gy >> 1) : gy, sx = UPS ? (gx >> 1) : gx;
                 srcoff[i] = ok ? unsigned(kGuard + (sy * Wi + sx) * kFPx + pxor[i]) : 0u; // 0 = the plane's zero guard
@@ -211,7 +231,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             if (uP >= S) return;
             const char* gbase = ((ckP < a.n0) ? plane_ptr(a.src0, itP.slot, ckP) : plane_ptr(a.src1, itP.slot, ckP - a.n0)) - kGuard;
             char* dst = smem + sP * kFPatch + lw * 1024;
-            if (!(a.dbg & (1 | 128))) // ablation: 1 = no LDS-DMA at all, 128 = no patch DMA, 64 = no weight DMA (stale LDS is multiplied)
+            if (!RSR_ABL(1 | 128)) // ablation (experiment builds): 1 = no LDS-DMA at all, 128 = no patch DMA, 64 = no weight DMA (stale LDS is multiplied)
             {
 #pragma unroll
                 for (int i = 0; i < NP; i++)
@@ -233,7 +253,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             if (uW >= S) return;
             const char* src = wsrc_lane + (long long)ckW * WB;
             char* dst = smem + kWOff + sW * WB + lw * 1024;
-            if (!(a.dbg & (1 | 64)))
+            if (!RSR_ABL(1 | 64))
             {
 #pragma unroll
                 for (int i = 0; i < (C::WPIECES + 3) / 4; i++)
@@ -249,14 +269,14 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             // every weight image of the conv, once, ahead of the first patch: vector loads retire in order, so "P(0) has landed"
             // implies "all weights have landed"
             const int npieces = nst * (EPI == 3 ? a.wpieces : C::WPIECES);
-            if (!(a.dbg & (1 | 64)))
+            if (!RSR_ABL(1 | 64))
                 for (int p_ = lw; p_ < npieces; p_ += 4)
                     __builtin_amdgcn_global_load_lds(RSR_GLB(static_cast<const char*>(a.wpk16) + p_ * 1024 + lane * 16), RSR_LDS(smem + kWOff + p_ * 1024), 16, 0, 0);
             for (int tt = -(PR - 1); tt < 0; tt++) issueP();
             // before E_t: P(t) and everything older has landed <=> at most the (PR - 2) newer patches are in flight
             for (int t = 0; t < S; t++)
             {
-                if ((a.dbg & 1) || t + PR - 2 >= S) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (RSR_ABL(1) || t + PR - 2 >= S) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 else if (PR == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(1 * NP) : "memory");
                 else if (PR == 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");
                 else if (PR == 5) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * NP) : "memory");
@@ -272,16 +292,17 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 if (tt + WR - 1 >= 0) issueW();
                 issueP();
             }
-            // counted wait immediates: nP + (WR-2)*(nW+nP) with nP = 5, WR = 3
+            // counted wait immediates: nP + (WR-2)*(nW+nP) with nP = 5
+            constexpr int WRm2 = C::WR - 2;
             constexpr int NW_HI = (C::WPIECES + 3) / 4, NW_LO = C::WPIECES / 4; // loader waves own NW_HI or NW_LO weight pieces
             for (int t = 0; t < S; t++)
             {
-                if ((a.dbg & 1) || t + PR - 2 >= S) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                else if (a.dbg & 64) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory"); // ablations: the same look-ahead
-                else if ((a.dbg & 128) && nW == NW_HI) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NW_HI) : "memory");
-                else if (a.dbg & 128) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NW_LO) : "memory");
-                else if (nW == NW_HI) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP + NW_HI) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP + NW_LO) : "memory");
+                if (RSR_ABL(1) || t + PR - 2 >= S) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                else if (RSR_ABL(64)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((WRm2 + 1) * NP) : "memory"); // ablations: the same look-ahead
+                else if (RSR_ABL(128) && nW == NW_HI) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WRm2 * NW_HI) : "memory");
+                else if (RSR_ABL(128)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WRm2 * NW_LO) : "memory");
+                else if (nW == NW_HI) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((WRm2 + 1) * NP + WRm2 * NW_HI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((WRm2 + 1) * NP + WRm2 * NW_LO) : "memory");
                 issueW();
                 issueP();
             }
@@ -345,20 +366,25 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     {
         char* base; // plane 2*ntw0 of the output slot
         int live;   // 0: stores are dropped (null resource)
-        int voff;   // lane's byte offset inside a plane row (or the out-of-range sentinel)
-        int y0, H, W, x0, slot;
+        int voff;   // lane's byte offset inside a plane row (+ 16 rows for the second strip of a folded block), or the out-of-range sentinel
+        int y0, H, W, slot;
+        unsigned lim; // bytes of one plane of this tile: H * W * 32
     };
     auto make_out = [&](const WorkItem& it, bool live) {
         OutDesc o;
         o.base = const_cast<char*>(plane_ptr(a.out16, it.slot, ntw0 * 2));
-        o.live = (live && !(a.dbg & 4)) ? 1 : 0;
-        const int x = it.x0 + l32;
-        o.voff = x < it.W ? x * kFPx + hi * 16 : int(0x80000000u);
+        o.live = (live && !RSR_ABL(4)) ? 1 : 0;
+        // lane -> pixel: column l32 of the block; in a FOLDED block column l32 & 15 of the strip l32 >> 4 (16 rows further down)
+        const bool fold = (it.x0 & kFoldBit) != 0;
+        const int x = (it.x0 & (kFoldBit - 1)) + (fold ? (l32 & 15) : l32);
+        o.voff = x < it.W ? x * kFPx + hi * 16 + ((fold && l32 >= 16) ? 16 * it.W * kFPx : 0) : int(0x80000000u);
         o.y0 = it.y0 + wrow * 4;
         o.H = it.H;
         o.W = it.W;
-        o.x0 = it.x0;
         o.slot = it.slot;
+        // every store / residual load of the block is range-checked against the END OF ITS PLANE (+ the plane's offset, which rides
+        // in the VGPR offset): rows below the tile -- of either strip of a folded block -- fall out by themselves
+        o.lim = unsigned(it.H) * unsigned(it.W * kFPx);
         return o;
     };
     // one finished row (32 px x 32 cout of an n-tile): scale / LeakyReLU, fp16; tq[p] = this lane's 16 bytes of output plane p
@@ -392,11 +418,14 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     auto res2_row = [&](u32x4 (&dst)[2], const OutDesc& o, int rr, int n) {
         const int y = o.y0 + rr;
         char* ub = uniform_ptr(const_cast<char*>(plane_ptr(a.res2, o.slot, ntw0 * 2)));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, y < o.H ? 0x7ffffff0 : 0, 0x00020000);
         const unsigned pstride = unsigned(a.res2.plane_stride);
 #pragma unroll
         for (int p = 0; p < 2; p++)
-            dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.voff, int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride), 0);
+        {
+            const unsigned poff = unsigned(n * 2 + p) * pstride;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, int(o.lim + poff), 0x00020000);
+            dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.voff, int(unsigned(y) * unsigned(o.W * kFPx) + poff), 0);
+        }
     };
     auto res2_prefetch = [&](const WorkItem& w, int row0) { // rows row0, row0 + 1
         if (!PRE2 || !has2) return;
@@ -412,7 +441,6 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     auto row_store = [&](const u32x4 (&tq)[2], const OutDesc& o, int rr, int n) {
         const int y = o.y0 + rr;
         char* ub = uniform_ptr(o.base);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
         const unsigned pstride = unsigned(a.out16.plane_stride);
         // The row / plane offset travels in the VGPR offset, soffset = 0: gfx950 needs 2 wait states between a > 64-bit
         // buffer store and a VALU write of its data registers ALSO when soffset is an SGPR, but hipcc only pads the
@@ -420,14 +448,17 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         // whenever the next row's arithmetic reused the registers right behind the store).  Out-of-image lanes keep bit 31.
 #pragma unroll
         for (int p = 0; p < 2; p++)
-            __builtin_amdgcn_raw_buffer_store_b128(tq[p], rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride), 0, 0);
+        {
+            const unsigned poff = unsigned(n * 2 + p) * pstride;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, o.live ? int(o.lim + poff) : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(tq[p], rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + poff), 0, 0);
+        }
     };
     // the inline epilogue of one row: plane by plane (pack -> residual -> store), so that only one 16-byte value is live at a time
     // (the 168-VGPR kernels have no room for a whole packed row next to the prefetched residual)
     auto row_emit = [&](const f32x16& acc, const OutDesc& o, int rr, int n) {
         const int y = o.y0 + rr;
         char* ub = uniform_ptr(o.base);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
         const unsigned pstride = unsigned(a.out16.plane_stride);
         u32x4 r2x[2];
         if (EPI == 2 && has2 && !PRE2) res2_row(r2x, o, rr, n);
@@ -456,7 +487,9 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (_Float16)((float)v[e] * a.s2 + (float)r2[e]);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(n * 2 + p) * pstride), 0, 0);
+            const unsigned poff = unsigned(n * 2 + p) * pstride;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, o.live ? int(o.lim + poff) : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + poff), 0, 0);
             __builtin_amdgcn_sched_barrier(0); // one plane at a time: interleaved, the two planes' temporaries do not fit the 168-VGPR kernels
         }
     };
@@ -464,15 +497,17 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // postproc_tiles), or -- non-TTA RGB -- straight into the uint8 image: realsr_postproc.comp:62-83 on the value rounded to
     // fp16 exactly as the planar path stores it (v*255 + 0.5, floor, clamp), at the tile's place minus the halo crop.
     auto store3 = [&](const float (&val)[4][3], const WorkItem& it) {
-        if (hi != 0 || ntw0 != 0 || (a.dbg & 4)) return;
-        const int x = it.x0 + l32;
+        if (hi != 0 || ntw0 != 0 || RSR_ABL(4)) return;
+        const bool fold = (it.x0 & kFoldBit) != 0; // lane -> pixel as in make_out
+        const int x = (it.x0 & (kFoldBit - 1)) + (fold ? (l32 & 15) : l32);
+        const int yb = it.y0 + wrow * 4 + ((fold && l32 >= 16) ? 16 : 0);
         if (a.out_u8)
         {
             const int ox = it.pad0 + x, ow = it.pad2 & 0xffff, oh = it.pad2 >> 16;
 #pragma unroll
             for (int rr = 0; rr < 4; rr++)
             {
-                const int y = it.y0 + wrow * 4 + rr;
+                const int y = yb + rr;
                 // (x - crop, y - crop) inside the un-padded rectangle  <=>  image pixel (pad0 + x, pad1 + y) inside the tile's box
                 const int rx = x - a.out_u8_crop, ry = y - a.out_u8_crop;
                 if (rx >= 0 && rx < ow && ry >= 0 && ry < oh)
@@ -495,7 +530,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
         for (int rr = 0; rr < 4; rr++)
         {
-            const int y = it.y0 + wrow * 4 + rr;
+            const int y = yb + rr;
             if (y < it.H && x < it.W)
             {
                 const long long pix = (long long)y * it.W + x;
@@ -722,6 +757,10 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // MFMAs + fragment reads are what buys clock.
     auto wave_is_dead = [&](const WorkItem& w) {
         const int y = w.y0 + wrow * 4;
+        // A folded block (kFoldBit) is judged by its FIRST strip alone: rows below the tile / inside the bottom margin hit the second
+        // strip whenever they hit the first, and the tables never fold a pair of block rows that reaches into the top margin
+        // (engine.cpp append_block_items) -- so this expression, whose exact shape the register allocation of every instantiation
+        // hangs on (+90 VGPRs and spills for a second pair of compares here, round 5), stays as it was.
         return (y >= w.H - a.margin || y + 4 <= a.margin) && !(a.dbg & 32);
     };
     auto skip_block = [&]() {
@@ -950,8 +989,9 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         auto row_store1 = [&](const u32x4& v, const OutDesc& o, int rr, int p) {
             const int y = o.y0 + rr;
             char* ub = uniform_ptr(o.base);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (o.live && y < o.H) ? 0x7ffffff0 : 0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + unsigned(p) * unsigned(a.out16.plane_stride)), 0, 0);
+            const unsigned poff = unsigned(p) * unsigned(a.out16.plane_stride);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, o.live ? int(o.lim + poff) : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + poff), 0, 0);
         };
 #include "conv_flow_hooks.inc" // RSR_HK_S<step>_<cell>: generated at build time by tools/gen_flow_hooks.py (Makefile)
     // A dead block first stores the pending set (the one a live block would drain underneath its MFMAs) -- once: `od` is dead
@@ -1060,26 +1100,26 @@ static hipError_t flow_attr()
 
 // patch ring depth a resident-weight launch can afford (0: the weights do not fit next to 3 patches)
 template <int NT>
-static int resident_ring(int nst)
+static int resident_ring(int nst, int reserve)
 {
-    const int rest = kLdsMax - nst * FlowCfg<NT>::WB - FlowCfg<NT>::SCR - NT * 128;
+    const int rest = kLdsMax - nst * FlowCfg<NT>::WB - reserve - NT * 128;
     const int pr = rest / kFPatch;
     return pr < 3 ? 0 : (pr > 6 ? 6 : pr);
 }
 
 template <int NT, int NTW, bool UPS, int EPI, bool DEFER>
-static void flow_launch(const ConvArgs& a_in, int ncu, bool resident, hipStream_t st)
+static void flow_launch(const ConvArgs& a_in, int ncu, bool resident, int reserve, hipStream_t st)
 {
     int grid = ncu & ~7;
     const int per = (a_in.nitems + 7) / 8;
     if (per * 8 < grid) grid = per * 8;
     const int nst = a_in.n0 + a_in.n1;
-    const int pr = resident ? resident_ring<NT>(nst) : 0; // (measured: a ring of 3 is as fast as one of 5 -- depth is not a limit)
+    const int pr = resident ? resident_ring<NT>(nst, reserve * NT) : 0; // (measured: a ring of 3 is as fast as one of 5 -- depth is not a limit)
     if (pr)
     {
         ConvArgs a = a_in;
         a.pr = pr;
-        const int lds = pr * kFPatch + nst * FlowCfg<NT>::WB + FlowCfg<NT>::SCR + NT * 128;
+        const int lds = pr * kFPatch + nst * FlowCfg<NT>::WB + NT * 128;
         hipLaunchKernelGGL((conv3x3_flow<NT, NTW, UPS, EPI, DEFER, true>), dim3(grid), dim3((4 * NT / NTW + 4) * 64), lds, st, a);
     }
     else
@@ -1131,12 +1171,13 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
     }
     else if ((!a.out_planar3 && !a.out_u8) || a.out16.base || a.res1_kind || a.res2_kind) return false;
     const bool ntw2 = (flags & 1) != 0, defer = !(flags & 2), res = !(flags & 4);
+    const int reserve = (flags & 16) ? 8192 : 0; // A/B aid: size the patch ring as if the rounds 1-3 transpose scratch (8 KB per n-tile) were still there
     if (nt == 1)
     {
         if (epi == 0 && !ups && a.waux && !(flags & 8))
         { // conv_last with (dy, cout) in the MFMA's M dimension: the 3-KB-per-plane aux image, always resident
             const int nst = a.n0 + a.n1;
-            int pr = (kLdsMax - nst * 3072 - FlowCfg<1>::SCR - 128) / kFPatch;
+            int pr = (kLdsMax - nst * 3072 - 128) / kFPatch;
             pr = pr > 6 ? 6 : pr;
             if (pr < 3) return false;
             a.wpk16 = a.waux;
@@ -1145,29 +1186,29 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
             int grid = ncu & ~7;
             const int per = (a.nitems + 7) / 8;
             if (per * 8 < grid) grid = per * 8;
-            hipLaunchKernelGGL((conv3x3_flow<1, 1, false, 3, false, true>), dim3(grid), dim3(512), pr * kFPatch + nst * 3072 + FlowCfg<1>::SCR + 128, st, a);
+            hipLaunchKernelGGL((conv3x3_flow<1, 1, false, 3, false, true>), dim3(grid), dim3(512), pr * kFPatch + nst * 3072 + 128, st, a);
         }
-        else if (epi == 0 && !ups) flow_launch<1, 1, false, 0, false>(a, ncu, res, st);
-        else if (epi == 1 && !ups && defer) flow_launch<1, 1, false, 1, true>(a, ncu, res, st);
-        else if (epi == 1 && !ups) flow_launch<1, 1, false, 1, false>(a, ncu, res, st);
-        else if (epi == 1) flow_launch<1, 1, true, 1, false>(a, ncu, res, st);
-        else if (epi == 2 && !ups) flow_launch<1, 1, false, 2, false>(a, ncu, res, st);
+        else if (epi == 0 && !ups) flow_launch<1, 1, false, 0, false>(a, ncu, res, reserve, st);
+        else if (epi == 1 && !ups && defer) flow_launch<1, 1, false, 1, true>(a, ncu, res, reserve, st);
+        else if (epi == 1 && !ups) flow_launch<1, 1, false, 1, false>(a, ncu, res, reserve, st);
+        else if (epi == 1) flow_launch<1, 1, true, 1, false>(a, ncu, res, reserve, st);
+        else if (epi == 2 && !ups) flow_launch<1, 1, false, 2, false>(a, ncu, res, reserve, st);
         else return false;
         return true;
     }
     if (nt != 2 || epi == 0) return false;
     if (ntw2)
     {
-        if (epi == 1 && !ups) flow_launch<2, 2, false, 1, false>(a, ncu, res, st);
-        else if (epi == 1) flow_launch<2, 2, true, 1, false>(a, ncu, res, st);
-        else if (!ups) flow_launch<2, 2, false, 2, false>(a, ncu, res, st);
+        if (epi == 1 && !ups) flow_launch<2, 2, false, 1, false>(a, ncu, res, reserve, st);
+        else if (epi == 1) flow_launch<2, 2, true, 1, false>(a, ncu, res, reserve, st);
+        else if (!ups) flow_launch<2, 2, false, 2, false>(a, ncu, res, reserve, st);
         else return false;
     }
     else
     {
-        if (epi == 1 && !ups) flow_launch<2, 1, false, 1, false>(a, ncu, res, st);
-        else if (epi == 1) flow_launch<2, 1, true, 1, false>(a, ncu, res, st);
-        else if (!ups) flow_launch<2, 1, false, 2, false>(a, ncu, res, st);
+        if (epi == 1 && !ups) flow_launch<2, 1, false, 1, false>(a, ncu, res, reserve, st);
+        else if (epi == 1) flow_launch<2, 1, true, 1, false>(a, ncu, res, reserve, st);
+        else if (!ups) flow_launch<2, 1, false, 2, false>(a, ncu, res, reserve, st);
         else return false;
     }
     return true;

@@ -276,11 +276,46 @@ static int tail_margin(int crop4, int which) // which: 0 conv_last, 1 HRconv, 2 
     return m > 0 ? m : 0;
 }
 
+// The work items of one H x W tile plane: 16 x 32 blocks row-major; blocks wholly inside the margin `m` (dead-output elimination)
+// are left out.  With `fold` a last column of 1..kFoldMaxW pixels is covered by FOLDED items (kernels.h), one per pair of block rows,
+// placed behind the second row of the pair: C3's 420-wide tiles 13 columns + 14 folded items instead of 14 x 27 blocks (-3.4 %),
+// the 140-wide edge tiles of C2 4 columns + 7 folded items instead of 5 x 14 (-10 %).  Tile geometry: realsr.cpp:170-181,246-249.
+// The kernel decides "these four rows need no matrix work" (wave_is_dead) from a folded block's FIRST strip alone; that is exact for
+// rows below the tile and for the bottom margin, and it would be wrong where the first strip lies in the TOP margin and the second
+// does not -- so pairs that start above `mtop` (the largest margin any conv of this level is launched with) stay plain blocks.
+void append_block_items(std::vector<WorkItem>& out, int slot, int H, int W, int m, int mtop, int p0, int p1, int p2, bool fold)
+{
+    const int rem = W % kBlkW;
+    const bool fold_last = fold && rem >= 1 && rem <= kFoldMaxW;
+    const int wfull = fold_last ? W - rem : W; // columns covered by plain blocks in every row
+    auto row_skipped = [&](int y0) { return y0 + kBlkH <= m || y0 >= H - m; };
+    auto plain_row = [&](int y0, int x_from, int x_to) {
+        for (int x0 = x_from; x0 < x_to; x0 += kBlkW)
+        {
+            if (row_skipped(y0) || x0 + kBlkW <= m || x0 >= W - m) continue; // nothing kept depends on it
+            out.push_back(WorkItem{slot, y0, x0, H, W, p0, p1, p2});
+        }
+    };
+    for (int y0 = 0; y0 < H; y0 += 2 * kBlkH) // pairs of block rows
+    {
+        const bool has2 = y0 + kBlkH < H;
+        const bool fold_pair = fold_last && y0 >= mtop;
+        plain_row(y0, 0, fold_pair ? wfull : W);
+        if (has2) plain_row(y0 + kBlkH, 0, fold_pair ? wfull : W);
+        if (fold_pair)
+        {
+            const bool dead = (row_skipped(y0) && (!has2 || row_skipped(y0 + kBlkH))) || wfull >= W - m;
+            if (!dead) out.push_back(WorkItem{slot, y0, wfull | kFoldBit, H, W, p0, p1, p2});
+        }
+    }
+}
+
 // place4 = prepadding * scale when the slots ARE the tiles (non-TTA: conv_last may write the image itself), < 0 otherwise
 // (TTA: 8 slots per tile, net_forward); trim4 = prepadding * scale when only the cropped rectangle is kept, 0 = keep all
-static void make_items(Plan::Batch& b, int place4 = -1, int trim4 = 0)
+static void make_items(Plan::Batch& b, bool fold, int place4 = -1, int trim4 = 0)
 {
     const int margin[3] = {0, tail_margin(trim4, 3), tail_margin(trim4, 2)}; // per level: the smallest margin of its convs
+    const int mtop[3] = {tail_margin(trim4, 4), tail_margin(trim4, 3), tail_margin(trim4, 0)}; // ... and the largest (append_block_items)
     for (int lvl = 0; lvl < 3; lvl++)
     {
         b.items[lvl].clear();
@@ -301,12 +336,7 @@ static void make_items(Plan::Batch& b, int place4 = -1, int trim4 = 0)
                 p1 = t.out_y - place4;
                 p2 = t.out_w | (t.out_h << 16);
             }
-            for (int y0 = 0; y0 < H; y0 += kBlkH)
-                for (int x0 = 0; x0 < W; x0 += kBlkW)
-                {
-                    if (y0 + kBlkH <= m || y0 >= H - m || x0 + kBlkW <= m || x0 >= W - m) continue; // nothing kept depends on it
-                    b.items[lvl].push_back(WorkItem{s, y0, x0, H, W, p0, p1, p2});
-                }
+            append_block_items(b.items[lvl], s, H, W, m, mtop[lvl], p0, p1, p2, fold);
         }
         b.item_start[lvl][size_t(b.nslots)] = int(b.items[lvl].size());
     }
@@ -385,7 +415,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
 {
     for (auto it = plans.begin(); it != plans.end(); ++it)
         if (it->w == w && it->h == h && it->c == c && it->T == tilesize && it->P == prepadding && it->tta == tta &&
-            it->tile0 == tile0 && it->tile1 == tile1 && it->budget_mb == max_workspace_mb && it->trim == trim_tail && it->xcd_order == xcd_order &&
+            it->tile0 == tile0 && it->tile1 == tile1 && it->budget_mb == max_workspace_mb && it->trim == trim_tail && it->xcd_order == xcd_order && it->fold == fold_cols &&
             it->clamp == ws_clamp_bytes)
         {
             plans.splice(plans.begin(), plans, it); // most recently used first
@@ -425,9 +455,11 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
             mth = std::max(mth, t.th);
         }
     // The kernels address a plane through 32-bit byte offsets (raw buffer resources, out-of-range sentinel 2^31): the
-    // largest plane is the 4x level, 16 * cap pixels * 64 B.  Tiles beyond that (~1,400 px) must be split by the caller.
-    if (cap * 16 * 64 >= (1ll << 31))
-        return fail(RSR_E_ARG, "tilesize too large: a padded tile may have at most 2,097,151 pixels (e.g. -t 1400)");
+    // largest plane is the 4x level, 16 * cap pixels * 32 B, and an MFMA wave reaches the 2 planes of its n-tile (4 with two n-tiles
+    // per wave, flow_flags bit 0) from one base; the stores' range limit is "end of the plane + the plane's offset" (conv_flow.hip
+    // make_out), which must stay below the sentinel too.  Tiles beyond that (~1,400 px) must be split by the caller.
+    if (cap * 16 * 32 * ((flow_flags & 1) ? 4 : 2) + 4 * kGuard >= (1ll << 31))
+        return fail(RSR_E_ARG, "tilesize too large: a padded tile may have at most 2,097,143 pixels (e.g. -t 1400)");
     const int per = tta ? 8 : 1;
     const long long per_slot = cap * kBytesPerPx;
     // Memory policy (the reference bounds device memory through the tile size alone, main.cpp:761-774; here ALL tiles of an image
@@ -452,6 +484,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
     plan.budget_mb = max_workspace_mb;
     plan.trim = trim_tail;
     plan.xcd_order = xcd_order;
+    plan.fold = fold_cols;
     plan.clamp = ws_clamp_bytes;
     plan.cap_px = cap;
     plan.max_tw = mtw;
@@ -473,7 +506,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
                 b.dims.push_back(k < 4 ? TileDim{t.th, t.tw} : TileDim{t.tw, t.th}); // realsr.cpp:251-258
         }
         b.trim4 = trim_tail ? P * scale : 0;
-        make_items(b, tta ? -1 : P * scale, b.trim4);
+        make_items(b, fold_cols, tta ? -1 : P * scale, b.trim4);
         table_bytes += batch_table_bytes(b);
         plan.batches.push_back(std::move(b));
     }
@@ -535,6 +568,15 @@ int Engine::ensure_workspace(int nslots, long long cap, hipStream_t st)
     bool any_grow = false;
     for (int i = 0; i < 6; i++)
         if (need[i] && !(bufs[i]->bytes >= need[i] && bufs[i]->p)) any_grow = true;
+    if (ws_fail_above_bytes >= 0)
+    { // test hook (option "ws_fail_above_mb"): a device on which workspaces above this size persistently fail to allocate
+        const long long total = (long long)nslots * cap * kBytesPerPx;
+        if (total > ws_fail_above_bytes)
+        {
+            ws_failures++;
+            return fail(RSR_E_NOMEM, "workspace of " + std::to_string(total >> 20) + " MiB refused (ws_fail_above_mb test hook)");
+        }
+    }
     if (any_grow || lc) HIP_TRY(hipStreamSynchronize(st)); // nothing in flight may use a buffer that is freed / re-laid-out
     int rc;
     // b_in: its second plane (channels 16..31 of the padded 3-channel input) must stay zero
@@ -807,9 +849,27 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
     if (tile1 < 0) tile1 = xtiles * ((h + tilesize - 1) / tilesize);
     int rc;
     // A clamp left behind by a transient allocation failure (another process held the memory for a moment) must not halve the
-    // batches for ever: when a NEW call finds that the device can give twice the clamped size again, it plans without it
-    // (never inside the retry loop below, which would then oscillate).  Plans are keyed by the clamp.
-    if (ws_clamp_bytes >= 0 && device_avail(w, h, c) >= 2 * ws_clamp_bytes) ws_clamp_bytes = -1;
+    // batches for ever: a NEW call that finds the device able to give twice the clamped size again plans without it (never inside
+    // the retry loop below, which would then oscillate).  But a PERSISTENT cause (fragmentation, hipMemGetInfo overstating what one
+    // hipMalloc can get) makes that test true on every call -- each frame would re-plan at full size, fail, drain the stream, free
+    // and rebuild the workspace.  So an un-clamp attempt is made at once only when the device reports clearly more room
+    // than it did at the moment of the failure (x 1.25), and otherwise at most once per `clamp_backoff` calls, the back-off doubling
+    // with every attempt that fails again.  Plans are keyed by the clamp.
+    bool unclamp_attempt = false;
+    if (ws_clamp_bytes >= 0)
+    {
+        const long long avail = device_avail(w, h, c);
+        if (avail >= 2 * ws_clamp_bytes)
+        {
+            const bool grown = clamp_fail_avail < 0 || avail >= clamp_fail_avail + clamp_fail_avail / 4;
+            if (grown || --clamp_calls_left <= 0)
+            {
+                clamp_saved = ws_clamp_bytes;
+                ws_clamp_bytes = -1;
+                unclamp_attempt = true;
+            }
+        }
+    }
     for (;;)
     {
         rc = get_plan(w, h, c, tile0, tile1, planp);
@@ -820,18 +880,26 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         const int per = tta ? 8 : 1;
         if (planp->slots_per_batch <= per) return rc;
         const std::string why = last_error();
-        const long long half_slots = std::max<long long>(per, (planp->slots_per_batch / 2) / per * per);
-        ws_clamp_bytes = half_slots * planp->cap_px * kBytesPerPx;
-        if (!clamp_logged)
-        {
-            clamp_logged = true;
-            std::fprintf(stderr, "realsr-hip: workspace of %d tile slots does not fit device %d (%s); batches halved to %lld slots\n",
-                         planp->slots_per_batch, device, why.c_str(), half_slots);
+        long long half_slots = std::max<long long>(per, (planp->slots_per_batch / 2) / per * per);
+        const long long failed_bytes = (long long)planp->slots_per_batch * planp->cap_px * kBytesPerPx;
+        clamp_fail_avail = device_avail(w, h, c);
+        if (unclamp_attempt && clamp_saved > 0 && clamp_saved < failed_bytes)
+        { // the clamp was right after all: back to it (not to half of the full size), and wait longer before the next try
+            half_slots = std::max<long long>(per, clamp_saved / (planp->cap_px * kBytesPerPx) / per * per);
+            clamp_backoff = std::min(clamp_backoff * 2, 1024);
         }
+        unclamp_attempt = false;
+        clamp_calls_left = clamp_backoff;
+        ws_clamp_bytes = half_slots * planp->cap_px * kBytesPerPx;
+        std::fprintf(stderr, "realsr-hip: workspace of %d tile slots (%.1f GB) does not fit device %d (%s); batches of %lld slots, next attempt at full size "
+                             "after %d calls or when the device reports > %.1f GB available\n",
+                     planp->slots_per_batch, double(failed_bytes) / 1e9, device, why.c_str(), half_slots, clamp_backoff,
+                     double(clamp_fail_avail) * 1.25 / 1e9);
         free_workspace(st); // partly grown buffers go back first; the stream is drained, so the plan's tables are idle too
         if (planp->d_tables) (void)hipFree(planp->d_tables);
         plans.pop_front(); // get_plan put it in front
     }
+    if (rc == RSR_OK && unclamp_attempt) { clamp_backoff = 4; clamp_fail_avail = -1; } // the full size fits again: forget the history
     if (rc != RSR_OK) return rc;
     const Plan& plan = *planp;
     constexpr int pc = plane_ch();
@@ -1203,9 +1271,9 @@ int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out)
     b.ntiles = 1;
     b.nslots = 1;
     b.dims.push_back(TileDim{h, w});
-    make_items(b);
+    make_items(b, fold_cols);
     const long long cap = (long long)w * h;
-    if (cap * 16 * 64 >= (1ll << 31)) return fail(RSR_E_ARG, "tile too large");
+    if (cap * 16 * 32 * ((flow_flags & 1) ? 4 : 2) + 4 * kGuard >= (1ll << 31)) return fail(RSR_E_ARG, "tile too large");
     DevBuf tab, tmp;
     auto cleanup = [&]() {
         if (tab.p) (void)hipFree(tab.p);
@@ -1277,8 +1345,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     // test_repeat > 1 (measurement aid): the same blocks N times in ONE launch -- after the first pass every patch and every
     // output line is in the L2s, i.e. the launch shows what this conv costs when nothing goes to HBM (tools/l2_bound_probe.py)
     for (int rep = 0; rep < std::max(1, test_repeat); rep++)
-        for (int y0 = 0; y0 < H; y0 += kBlkH)
-            for (int x0 = 0; x0 < W; x0 += kBlkW) items.push_back(WorkItem{0, y0, x0, H, W, 0, 0, 0});
+        append_block_items(items, 0, H, W, 0, 0, 0, 0, 0, fold_cols);
     const TileDim td{h, w};
     auto cleanup = [&]() {
         for (DevBuf* b : {&d_w, &d_in, &d_out, &d_tab, &d_res})

@@ -42,7 +42,7 @@ struct Plan
     int w = 0, h = 0, c = 0, T = 0, P = 0, tta = 0;
     int tile0 = 0, tile1 = 0; // tiles [tile0, tile1) of the image's tile grid, row-major (multi-GPU tile sharding)
     long long budget_mb = 0;
-    bool trim = true, xcd_order = true;
+    bool trim = true, xcd_order = true, fold = true;
     long long clamp = -1; // Engine::ws_clamp_bytes when the plan was built (part of the cache key)
     long long cap_px = 0; // slot capacity in LR pixels
     int max_tw = 0, max_th = 0;
@@ -111,6 +111,7 @@ struct Engine
     int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
     bool trim_tail = true; // leave out the blocks / rows behind the trunk that only feed cropped output pixels (engine.cpp: tail_margin)
     bool xcd_order = true; // backward work-item tables reversed per XCD share (each XCD re-reads what IT wrote last: L2 hits), else as a whole
+    bool fold_cols = true; // a tile's last column of <= 14 pixels as folded work items (kernels.h: kFoldBit); off = one plain block column more
     bool alternate_order = true; // odd convs walk the work items backwards: they start on the data the previous conv touched last
     int test_repeat = 1;        // conv_test: work items repeated N times in one launch (measurement aid)
     double last_test_us = 0.0;  // HIP-event time of the last conv_test launch
@@ -119,7 +120,12 @@ struct Engine
     long long max_workspace_mb = 65536;
     long long ws_clamp_bytes = -1; // set after a workspace allocation failed: the next plans stay below it (-1 = none); dropped
                                    // again when the device can give twice that much (get_plan)
-    bool clamp_logged = false;     // the halving is reported on stderr once per context
+    long long clamp_fail_avail = -1; // device_avail() at the moment of the last failed workspace allocation (-1: the clamp was planted by the test hook)
+    long long clamp_saved = -1;      // the clamp an un-clamp attempt set aside (restored when the attempt fails)
+    int clamp_backoff = 4;           // calls between two un-clamp attempts while the device does not report clearly more room; doubles per failed attempt
+    int clamp_calls_left = 0;
+    long long ws_fail_above_bytes = -1; // test hook: workspaces above this size fail with RSR_E_NOMEM (a persistently fragmented device)
+    long long ws_failures = 0;          // ... how often it fired (stat "ws_failures")
     int tail_group_slots = 0; // slots per launch group of the 2x / 4x convs (0 = the whole batch at once), see run_network
     int max_lanes = 4;
     size_t chunk_bytes = size_t(16) << 20; // download chunk for pageable destinations

@@ -20,9 +20,17 @@ constexpr int kPatchPx = kPatchH * kPatchW;     // 612
 constexpr int kGuard = 64;                      // zero bytes in front of every conv-input plane (LDS-DMA source for padding)
 constexpr int kPlaneCh = 16;                    // channels per plane
 
+// FOLDED blocks.  A tile whose width leaves a remainder of 1..kFoldMaxW columns behind its last full 32-column block would spend a
+// whole block (32-pixel MFMA rows) on those few columns: C3's 420-wide tiles 14 block columns for 13.1, +6.7 % executed matrix
+// work.  Such a last column is covered by folded work items instead: ONE block = that column over TWO block rows (rows y0..y0+15
+// in lanes / patch columns 0..15, rows y0+16..y0+31 in 16..31).  The matrix loop is unchanged -- lanes never look across pixels --
+// only the loaders' gather and the epilogue's scatter know (conv_flow.hip).  WorkItem::x0 carries the flag in bit 30.
+constexpr int kFoldBit = 1 << 30;
+constexpr int kFoldMaxW = 14; // strip = left halo + <= 14 pixels + right halo = 16 patch columns
+
 struct WorkItem // 32 bytes: one aligned 2 x 16-byte fetch gives a workgroup everything about its block
 {
-    int slot, y0, x0; // tile slot and block origin at this table's resolution level
+    int slot, y0, x0; // tile slot and block origin at this table's resolution level (x0 | kFoldBit: a folded block)
     int H, W;         // dims of the slot's tile at this level (output dims of the conv)
     // 4x-level items of a non-TTA batch: image coordinates of tile pixel (0,0) (= out_x - crop, out_y - crop; may be negative)
     // and the size of the tile's un-padded output rectangle, out_w | out_h << 16  (conv_last writes the image itself)

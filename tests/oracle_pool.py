@@ -6,9 +6,11 @@ tile = 1.7 TFLOP of fp32 CPU work = ~4.5 s on 16 cores).
 ref_tiles(pp, bp, [(padded CHW float32 tile, tta)]) -> [uint8 (4*th, 4*tw, 3) of the un-padded rectangle]
 following realsr.cpp:525-838: network on the halo'd tile (x8 dihedral variants under TTA, realsr.cpp:617-724, merged
 (sum) * 0.125), crop prepadding * 4, v * 255 + 0.5, truncate, clamp."""
+import hashlib
 import multiprocessing as mp
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -122,3 +124,54 @@ def check_frame_tiles(out, img, pp, bp, T, tiles=None, tta=False, P=10):
         diff += int((d > 0).sum())
         total += d.size
     return len(geo), diff / max(total, 1)
+
+
+# ---- whole BASELINE frames: committed strided oracle samples + a rotating live subset ------------------------------------
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def check_frame_golden(out, name, img, bin_path, T):
+    """Compare EVERY tile of the engine's frame `out` with the committed oracle samples tests/golden/frame_<name>.npz (the oracle's
+    uint8 output on a lattice of every 8th row / column + every 64th at phase 7, written by tests/golden/make_frames.py), +-1.
+    The file names the image and the weights it was made from; both are checked.  Returns (tiles covered, fraction of differing
+    samples)."""
+    z = np.load(os.path.join(GOLDEN, "frame_%s.npz" % name))
+    assert hashlib.sha256(img.tobytes()).digest() == z["img_sha256"].tobytes(), "golden samples were made from another image"
+    assert hashlib.sha256(open(bin_path, "rb").read()).digest() == z["bin_sha256"].tobytes(), "golden samples were made from other weights"
+    rows, cols, ref = z["rows"], z["cols"], z["samples"].astype(np.int16)
+    got = out[rows][:, cols, :3].astype(np.int16)
+    assert got.shape == ref.shape
+    d = np.abs(got - ref)
+    h, w = img.shape[:2]
+    xt, yt = (w + T - 1) // T, (h + T - 1) // T
+    covered = 0
+    for yi in range(yt):
+        for xi in range(xt):
+            r = (rows >= 4 * yi * T) & (rows < 4 * min((yi + 1) * T, h))
+            c = (cols >= 4 * xi * T) & (cols < 4 * min((xi + 1) * T, w))
+            assert r.sum() >= 4 and c.sum() >= 4, "tile (%d,%d) has too few samples" % (xi, yi)
+            dt = d[r][:, c]
+            assert dt.max() <= 1, "tile (%d,%d): max diff %d vs the golden oracle samples" % (xi, yi, dt.max())
+            covered += 1
+    return covered, float((d > 0).mean())
+
+
+def rotating_tiles(xt, yt, k=6):
+    """k tiles of an xt x yt grid for the LIVE oracle: the corner, one of the last column, two of the last row (the three edge-tile
+    shapes) and interior ones; which ones rotates with the calendar day (RSR_ROTATE=<int> pins it), so that successive runs walk
+    over the frame while a single run stays short."""
+    seed = int(os.environ.get("RSR_ROTATE", int(time.time() // 86400)))
+    rng = np.random.default_rng(seed)
+    tiles = [(xt - 1, yt - 1)]
+    if yt > 1:
+        tiles.append((xt - 1, int(rng.integers(0, yt - 1))))
+    if xt > 1:
+        for xi in rng.choice(xt - 1, size=min(2, xt - 1), replace=False):
+            tiles.append((int(xi), yt - 1))
+    inner = [(xi, yi) for yi in range(max(1, yt - 1)) for xi in range(max(1, xt - 1))]
+    for i in rng.permutation(len(inner)):
+        if len(tiles) >= k:
+            break
+        if inner[i] not in tiles:
+            tiles.append(inner[i])
+    return tiles[:k]

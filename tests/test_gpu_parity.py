@@ -99,6 +99,42 @@ def test_rows_below_the_tile_are_skipped_not_miscomputed(sr, cin, cout, h, w, up
             sr.set_option(k, v)
 
 
+@pytest.mark.parametrize("cin,cout,h,w,ups", [(64, 32, 40, 44, False), (160, 32, 52, 36, False), (192, 64, 36, 46, False), (96, 32, 70, 10, False),
+                                              (64, 64, 22, 19, True), (64, 3, 41, 34, False), (128, 32, 17, 33, False)])
+def test_folded_blocks_equal_plain_blocks(sr, cin, cout, h, w, ups):
+    """A tile's last block column of 1..14 pixels runs as FOLDED work items (kernels.h kFoldBit: two block rows of the narrow column
+    in one 16 x 32 block; 420 = 13 x 32 + 4, 260 = 8 x 32 + 4, 140 = 4 x 32 + 12 are the padded tile widths of BASELINE C3 / C2,
+    realsr.cpp:170-181,246-249).  Only the loaders' gather and the epilogue's scatter differ, every output value is accumulated in the
+    same order: option "fold" 0 (one plain block column more) must give the SAME BYTES.  Heights whose second strip is partly /
+    wholly below the tile, an unpaired last block row, a tile narrower than one block, the nearest-x2 gather, conv_last in both
+    forms, every wave layout, few workgroups (a workgroup then meets folded and plain blocks back to back)."""
+    rng = np.random.default_rng(cin + 11 * w)
+    x = rng.standard_normal((cin, h, w)).astype(np.float16)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    try:
+        for flags in ((0, 8) if cout == 3 else (0, 1, 2, 3, 4)):
+            for ncu in (256, 8):
+                sr.set_option("flow_flags", flags)
+                sr.set_option("num_cu", ncu)
+                sr.set_option("fold", 0)
+                ref = sr.conv3x3(x, wt, b, lrelu=(cout != 3), upsample2x=ups)
+                sr.set_option("fold", 1)
+                got = sr.conv3x3(x, wt, b, lrelu=(cout != 3), upsample2x=ups)
+                assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), (flags, ncu)
+                if cout == 64 and not ups:  # the residual epilogues fetch / add through the same lane -> pixel map
+                    res = rng.standard_normal((cout, h, w)).astype(np.float16)
+                    for s1, own, rr, s2 in ((0.2, True, None, 1.0), (0.2, True, res, 0.2), (1.0, False, res, 1.0)):
+                        sr.set_option("fold", 0)
+                        ref = sr.conv3x3_res(x, wt, b, s1, own_input_residual=own, res=rr, s2=s2)
+                        sr.set_option("fold", 1)
+                        got = sr.conv3x3_res(x, wt, b, s1, own_input_residual=own, res=rr, s2=s2)
+                        assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), (flags, ncu, s1, own, s2)
+    finally:
+        for k, v in (("flow_flags", 0), ("fold", 1), ("num_cu", 256)):
+            sr.set_option(k, v)
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(192, 64, 20, 40), (64, 64, 33, 50), (192, 64, 70, 90)])
 def test_residual_epilogues_match_numpy(sr, cin, cout, h, w):
     """The Eltwise / BinaryOp layers behind a Convolution in x4.param, fused into its epilogue: RDB conv5

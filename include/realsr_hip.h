@@ -88,7 +88,8 @@ void rsr_host_free(void* p);
 int rsr_device_memory(int gpuid, long long* free_mb, long long* total_mb);
 
 /* The reference prints one line per tile to stderr (realsr.cpp:481).  Here all tiles of a batch run together: `cb` is
- * called (from the calling thread, kernels enqueued but not necessarily finished) after each tile batch. */
+ * called once per TILE (tiles_done = 1 .. tiles_total, from the calling thread) when the tile's batch has been enqueued --
+ * kernels not necessarily finished; the calls of one batch arrive back to back. */
 int rsr_set_progress_callback(rsr_ctx* ctx, void (*cb)(int tiles_done, int tiles_total, void* user), void* user);
 
 /* ---- weights as one relocatable blob (multi-GPU load path) -------------------------------- */
@@ -241,7 +242,7 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "ws_clamp_mb"       test hook: plant the workspace bound a failed allocation leaves behind (< 0 clears it; see rsr_get_stat)
  *   "ws_fail_above_mb"  test hook: workspaces above this size fail to allocate, every time (a persistently fragmented device; < 0 off);
  *                       stat "ws_failures" counts the refusals, "clamp_backoff" the calls between two attempts at the full size
- *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; -DRSR_FLOW_TRACE builds), -1 off
+ *   "trace_conv"        conv index whose launch records s_memtime stamps (rsr_get_trace; -DRSR_EXPERIMENT -DRSR_FLOW_TRACE builds), -1 off
  *   "alternate_order"   1 [default]: every second conv walks its work items backwards (starts on the tiles the previous conv
  *                       touched last -> Infinity Cache hits); 0: always forwards
  *   "xcd_order"         1 [default]: the backward tables of "alternate_order" are reversed inside each XCD's share of the list, so an XCD

@@ -351,7 +351,7 @@ int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value)
     auto lanes_bytes = [&](bool out) {
         std::lock_guard<std::mutex> ll(e.lane_mu);
         double n = 0;
-        for (const auto& l : e.lanes) n += double(out ? l->d_out.bytes : l->d_in.bytes);
+        for (const auto& l : e.lanes) n += double(out ? l->out_bytes.load(std::memory_order_relaxed) : l->in_bytes.load(std::memory_order_relaxed));
         return n;
     };
     if (k == "plan_batches") *value = e.plans.empty() ? 0.0 : double(e.plans.front().batches.size());
@@ -359,6 +359,8 @@ int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value)
     else if (k == "plans") *value = double(e.plans.size());
     else if (k == "ws_clamp_mb") *value = e.ws_clamp_bytes < 0 ? -1.0 : double(e.ws_clamp_bytes) / 1048576.0;
     else if (k == "ws_failures") *value = double(e.ws_failures);
+    else if (k == "pool_workers") *value = double(share_pool_stat(0));
+    else if (k == "pool_inline_runs") *value = double(share_pool_stat(1));
     else if (k == "clamp_backoff") *value = double(e.clamp_backoff);
     else if (k == "workspace_mb")
     {

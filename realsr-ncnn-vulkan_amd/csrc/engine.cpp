@@ -312,7 +312,7 @@ void append_block_items(std::vector<WorkItem>& out, int slot, int H, int W, int 
 
 // place4 = prepadding * scale when the slots ARE the tiles (non-TTA: conv_last may write the image itself), < 0 otherwise
 // (TTA: 8 slots per tile, net_forward); trim4 = prepadding * scale when only the cropped rectangle is kept, 0 = keep all
-static void make_items(Plan::Batch& b, bool fold, int place4 = -1, int trim4 = 0)
+static void make_items(Plan::Batch& b, bool fold, int place4 = -1, int trim4 = 0, int out_row0 = 0)
 {
     const int margin[3] = {0, tail_margin(trim4, 3), tail_margin(trim4, 2)}; // per level: the smallest margin of its convs
     const int mtop[3] = {tail_margin(trim4, 4), tail_margin(trim4, 3), tail_margin(trim4, 0)}; // ... and the largest (append_block_items)
@@ -333,7 +333,7 @@ static void make_items(Plan::Batch& b, bool fold, int place4 = -1, int trim4 = 0
             {
                 const BaseTile& t = b.tiles[size_t(s)];
                 p0 = t.out_x - place4;
-                p1 = t.out_y - place4;
+                p1 = t.out_y - out_row0 - place4; // rows relative to the first output row the caller's device buffer holds
                 p2 = t.out_w | (t.out_h << 16);
             }
             append_block_items(b.items[lvl], s, H, W, m, mtop[lvl], p0, p1, p2, fold);
@@ -405,7 +405,7 @@ long long Engine::device_avail(int w, int h, int c)
     long long lanes_have = 0;
     {
         std::lock_guard<std::mutex> ll(lane_mu);
-        for (const auto& l : lanes) lanes_have += (long long)(l->d_in.bytes + l->d_out.bytes);
+        for (const auto& l : lanes) lanes_have += (long long)(l->in_bytes.load(std::memory_order_relaxed) + l->out_bytes.load(std::memory_order_relaxed));
     }
     const long long lanes_need = std::max<long long>(0, (long long)max_lanes * 17 * w * h * c - lanes_have);
     return std::max<long long>(0, ((long long)f + held) / 10 * 9 - lanes_need);
@@ -485,6 +485,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
     plan.trim = trim_tail;
     plan.xcd_order = xcd_order;
     plan.fold = fold_cols;
+    plan.out_row0 = std::min((tile0 / xtiles) * T, h) * scale; // first output row of the range's first tile row
     plan.clamp = ws_clamp_bytes;
     plan.cap_px = cap;
     plan.max_tw = mtw;
@@ -506,7 +507,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
                 b.dims.push_back(k < 4 ? TileDim{t.th, t.tw} : TileDim{t.tw, t.th}); // realsr.cpp:251-258
         }
         b.trim4 = trim_tail ? P * scale : 0;
-        make_items(b, fold_cols, tta ? -1 : P * scale, b.trim4);
+        make_items(b, fold_cols, tta ? -1 : P * scale, b.trim4, plan.out_row0);
         table_bytes += batch_table_bytes(b);
         plan.batches.push_back(std::move(b));
     }
@@ -936,8 +937,9 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         }
         rc = run_network(b, st, fused ? static_cast<uint8_t*>(d_out) : nullptr, w * scale, split_slot, ev_half);
         if (rc != RSR_OK) return rc;
+        if (progress) // one call per TILE, like the reference's line per tile (realsr.cpp:481), issued when the tile's batch is enqueued
+            for (int i = 1; i <= b.ntiles; i++) progress(done + i, total, progress_user);
         done += b.ntiles;
-        if (progress) progress(done, total, progress_user);
         if (fused) continue;
         PostArgs po;
         po.planar3 = b_out3.p;
@@ -948,6 +950,7 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         po.crop = prepadding * scale;
         po.out = static_cast<uint8_t*>(d_out);
         po.out_w = w * scale; po.out_h = h * scale; po.c = c;
+        po.out_row0 = plan.out_row0;
         po.in_img = static_cast<const uint8_t*>(d_in);
         po.in_w = w; po.in_h = h;
         po.tilesize = tilesize;
@@ -1121,7 +1124,12 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     const int r0 = tile0 / xtiles, c0 = tile0 % xtiles, r1 = (tile1 - 1) / xtiles, c1 = (tile1 - 1) % xtiles + 1; // last tile = (r1, c1 - 1)
     const size_t base_off = yof(r0) * rowbytes;
     if ((rc = ensure(L->d_out, (yof(r1 + 1) - yof(r0)) * rowbytes)) != RSR_OK) return rc;
-    char* const vout = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(L->d_out.p) - base_off); // where output row 0 would be
+    L->in_bytes.store(L->d_in.bytes, std::memory_order_relaxed); // what device_avail() / rsr_get_stat read (they do not hold this lane)
+    L->out_bytes.store(L->d_out.bytes, std::memory_order_relaxed);
+    // the kernels get the REAL base of the allocation: the plan of a tile range places its tiles relative to the range's first
+    // output row (Plan::out_row0 == yof(r0), get_plan); dev(off) = device address of byte `off` of the full-size image
+    char* const dbase = static_cast<char*>(L->d_out.p);
+    auto dev = [&](size_t off) { return dbase + (off - base_off); };
 
     // ---- upload ----
     const void* src = in;
@@ -1141,7 +1149,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
         if (!loaded || scale != 4 || tilesize != T)
             return fail(RSR_E_STATE, "context parameters changed while the call was in flight"); // (the guard drains the upload)
         HIP_TRY(hipStreamWaitEvent(stream, L->ev_in, 0));
-        rc = enqueue_image(L->d_in.p, w, h, c, vout, stream, tile0, tile1, L->ev_half, &half_rows);
+        rc = enqueue_image(L->d_in.p, w, h, c, dbase, stream, tile0, tile1, L->ev_half, &half_rows);
         if (rc != RSR_OK)
         {
             (void)hipStreamSynchronize(stream); // kernels of this call that did get enqueued use the lane buffers
@@ -1165,7 +1173,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
             if (pinned)
             {
                 const size_t off = y_a * rowbytes + x_a;
-                HIP_TRY(hipMemcpy2DAsync(out + off, rowbytes, vout + off, rowbytes, wb, y_b - y_a, hipMemcpyDeviceToHost, L->copy));
+                HIP_TRY(hipMemcpy2DAsync(out + off, rowbytes, dev(off), rowbytes, wb, y_b - y_a, hipMemcpyDeviceToHost, L->copy));
                 return RSR_OK;
             }
             const size_t half = L->h_out_bytes / 2, rows_per = std::max<size_t>(1, half / wb);
@@ -1176,7 +1184,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
                 if (i < nch)
                 {
                     const size_t ya = y_a + i * rows_per, nr = std::min(rows_per, y_b - ya);
-                    HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(L->h_out) + (i & 1) * half, wb, vout + ya * rowbytes + x_a, rowbytes, wb, nr,
+                    HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(L->h_out) + (i & 1) * half, wb, dev(ya * rowbytes + x_a), rowbytes, wb, nr,
                                              hipMemcpyDeviceToHost, L->copy));
                     HIP_TRY(hipEventRecord(L->ev_chunk[i & 1], L->copy));
                 }
@@ -1217,7 +1225,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     const bool pinned_out = is_pinned_host(out);
     if (pinned_out)
     {
-        const char* dsrc = vout + out_off;
+        const char* dsrc = dev(out_off);
         if (first)
         {
             HIP_TRY(hipStreamWaitEvent(L->copy, L->ev_half, 0));
@@ -1233,7 +1241,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     if ((rc = ensure_pinned(L->h_out, L->h_out_bytes, 2 * std::min(CH, nout))) != RSR_OK) return rc;
     const size_t half = L->h_out_bytes / 2;
     const size_t nchunks = (nout + half - 1) / half;
-    const char* dsrc = vout + out_off;
+    const char* dsrc = dev(out_off);
     bool waited_done = false;
     for (size_t i = 0; i <= nchunks; i++)
     {

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <list>
@@ -43,6 +44,7 @@ struct Plan
     int tile0 = 0, tile1 = 0; // tiles [tile0, tile1) of the image's tile grid, row-major (multi-GPU tile sharding)
     long long budget_mb = 0;
     bool trim = true, xcd_order = true, fold = true;
+    int out_row0 = 0; // output rows are addressed relative to this one: the first row of the tile range (the device buffer of a range holds only its rows)
     long long clamp = -1; // Engine::ws_clamp_bytes when the plan was built (part of the cache key)
     long long cap_px = 0; // slot capacity in LR pixels
     int max_tw = 0, max_th = 0;
@@ -92,6 +94,7 @@ struct Lane
     hipStream_t copy = nullptr;
     hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_half = nullptr, ev_chunk[2] = {nullptr, nullptr};
     DevBuf d_in, d_out;
+    std::atomic<size_t> in_bytes{0}, out_bytes{0}; // sizes of d_in / d_out for readers that do not own the lane (device_avail, rsr_get_stat)
     void* h_in = nullptr;
     size_t h_in_bytes = 0;
     void* h_out = nullptr; // two download chunks
@@ -213,6 +216,7 @@ struct Engine
 };
 
 const char* last_error(); // message of the calling thread's last failure
+long long share_pool_stat(int what); // group.cpp: 0 = worker threads of rsr_process_group's pool, 1 = shares run inline because no worker could be started
 
 } // namespace rsr
 

@@ -6,6 +6,7 @@
 // RCCL is resolved with dlopen at run time: the library has no link-time dependency on it, a process that already
 // carries an RCCL (PyTorch) shares that copy, and a single-GPU user never loads it.
 #include <dlfcn.h>
+#include <pthread.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -16,6 +17,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -67,6 +69,11 @@ thread_local std::string g_transport = "none";
 
 // Worker threads of rsr_process_group, kept between calls (one image = one call: starting `parts` fresh threads per image
 // costs as much as a few tiles).  A worker is added only when a job finds none idle; the calling thread always runs share 0 itself.
+// Robustness: a worker that cannot be created (std::system_error: thread limit, no memory) must not throw across the
+// extern "C" boundary with the job already queued -- the job is taken back and run on the CALLING thread.  The pool lives on the heap
+// and is never destroyed: a process exits without joining workers that sleep on a condition variable, and a fork()ed child (whose
+// copy of the pool would name threads that do not exist there, so run() would wait for ever and a destructor would join nothing)
+// gets a fresh, empty pool from a pthread_atfork child handler.
 struct SharePool
 {
     std::mutex m;
@@ -74,46 +81,79 @@ struct SharePool
     std::deque<std::function<void()>> q;
     std::vector<std::thread> workers;
     int idle = 0;
-    bool stop = false;
+    int inline_runs = 0; // jobs run on the caller's thread because no worker could be started (statistics / tests)
     void run(std::function<void()> f)
     {
+        bool run_here = false;
         {
             std::lock_guard<std::mutex> lk(m);
             q.push_back(std::move(f));
             if (int(q.size()) > idle && workers.size() < 64) // nobody free for this job: one more worker (64 = more GPUs than a node has)
-                workers.emplace_back([this] {
-                    std::unique_lock<std::mutex> lk(m);
-                    for (;;)
+            {
+                try
+                {
+                    if (std::getenv("RSR_POOL_NO_THREADS")) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again)); // test hook
+                    workers.emplace_back([this] {
+                        std::unique_lock<std::mutex> lk(m);
+                        for (;;)
+                        {
+                            idle++;
+                            cv.wait(lk, [this] { return !q.empty(); });
+                            idle--;
+                            std::function<void()> job = std::move(q.front());
+                            q.pop_front();
+                            lk.unlock();
+                            job();
+                            lk.lock();
+                        }
+                    });
+                }
+                catch (const std::system_error&)
+                {
+                    if (int(q.size()) > idle) // nobody will pick it up soon: take the job back (it is the newest) and run it here
                     {
-                        idle++;
-                        cv.wait(lk, [this] { return stop || !q.empty(); });
-                        idle--;
-                        if (q.empty()) return;
-                        std::function<void()> job = std::move(q.front());
-                        q.pop_front();
-                        lk.unlock();
-                        job();
-                        lk.lock();
+                        f = std::move(q.back());
+                        q.pop_back();
+                        run_here = true;
+                        inline_runs++;
                     }
-                });
+                }
+            }
         }
-        cv.notify_one();
-    }
-    ~SharePool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            stop = true;
-        }
-        cv.notify_all();
-        for (std::thread& t : workers) t.join();
+        if (run_here) f();
+        else cv.notify_one();
     }
 };
-SharePool& share_pool()
+SharePool*& share_pool_ptr()
 {
-    static SharePool p;
+    static SharePool* p = nullptr;
     return p;
 }
+SharePool& share_pool()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        share_pool_ptr() = new SharePool;
+        // the parent's workers do not exist in a forked child: start over with an empty pool (the old object is leaked on purpose --
+        // its mutex may have been held by a thread that is gone)
+        (void)pthread_atfork(nullptr, nullptr, [] { share_pool_ptr() = new SharePool; });
+    });
+    return *share_pool_ptr();
+}
+
+} // namespace
+
+namespace rsr {
+// rsr_get_stat "pool_workers" / "pool_inline_runs" (process-wide)
+long long share_pool_stat(int what)
+{
+    SharePool& p = share_pool();
+    std::lock_guard<std::mutex> lk(p.m);
+    return what == 0 ? (long long)p.workers.size() : (long long)p.inline_runs;
+}
+} // namespace rsr
+
+namespace {
 
 // dst[i] (device i, `bytes` each) <- src on device gpuids[0], one broadcast.  false + why on any failure.
 bool rccl_broadcast(const int* gpuids, int n, const void* src, void* const* dst, size_t bytes, std::string& why)
@@ -207,6 +247,24 @@ int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, cons
             destroy_all();
             return rc;
         }
+    }
+    // First contact with a node of several GPUs: every member's workspace budget (default 64 GiB) is capped HERE by what ITS device can
+    // give right now -- 90 % of the free memory behind a reserve for the image buffers of its lanes (a 4K frame: 4 x 0.5 GB) -- and
+    // said once, so that a device another job already fills shows up at creation and not as a failed allocation inside the first frame
+    // (the engine re-checks at every plan and halves the batch if an allocation still fails: engine.cpp get_plan / enqueue_image).
+    for (int i = 0; i < n; i++)
+    {
+        size_t f = 0, t = 0;
+        if (hipSetDevice(gpuids[i]) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); continue; }
+        Engine& e = out[i]->e;
+        std::lock_guard<std::mutex> lk(e.mu);
+        const long long room_mb = (long long)(f / 10 * 9 >> 20) - 2048;
+        const long long before = e.max_workspace_mb;
+        e.max_workspace_mb = std::max<long long>(1024, std::min(before, room_mb));
+        if (e.max_workspace_mb < before || std::getenv("RSR_VERBOSE"))
+            std::fprintf(stderr, "realsr-hip: group member %d on device %d: %.1f of %.1f GiB free, workspace budget %.1f GiB%s\n", i, gpuids[i],
+                         double(f) / 1073741824.0, double(t) / 1073741824.0, double(e.max_workspace_mb) / 1024.0,
+                         e.max_workspace_mb < before ? " (capped by the device's free memory)" : "");
     }
     g_transport = "host";
     bool done = false;

@@ -134,6 +134,7 @@ struct PostArgs
     int crop;   // prepadding*scale
     uint8_t* out; // HWC u8 (4w x 4h x c)
     int out_w, out_h, c;
+    int out_row0; // `out` points at output row out_row0 of the x4 image (a tile range's device buffer holds only its rows)
     const uint8_t* in_img; // for alpha (c==4): source image (w x h x 4)
     int in_w, in_h;
     int tilesize;

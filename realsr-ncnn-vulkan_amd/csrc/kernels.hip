@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
     const int w = t.tw * 4, h = t.th * 4;
     const long long cstep = (long long)w * h;
     const int sx = gx + a.crop, sy = gy + a.crop;
-    uint8_t* o = a.out + ((long long)(t.out_y + gy) * a.out_w + t.out_x + gx) * a.c;
+    uint8_t* o = a.out + ((long long)(t.out_y - a.out_row0 + gy) * a.out_w + t.out_x + gx) * a.c;
     const _Float16* b0 = reinterpret_cast<const _Float16*>(static_cast<const char*>(a.planar3) + (long long)t.slot0 * a.slot_stride);
     float v[3];
     if (!a.tta)
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
     for (int i = tid; i < ny * nd; i += 256)
     {
         const int r = i / nd, d = i - r * nd;
-        uint8_t* o = a.out + ((long long)(t.out_y + gy0 + r) * a.out_w + t.out_x + gx0) * a.c;
+        uint8_t* o = a.out + ((long long)(t.out_y - a.out_row0 + gy0 + r) * a.out_w + t.out_x + gx0) * a.c;
         reinterpret_cast<uint32_t*>(o)[d] = reinterpret_cast<const uint32_t*>(&ob[r][0])[d];
     }
 }

@@ -327,9 +327,9 @@ int main(int argc, char** argv)
         r->scale = scale;
         r->tilesize = tilesize[size_t(i)];
         r->prepadding = prepadding;
-        // the reference prints the progress of every tile (realsr.cpp:481); here a batch of tiles runs at once
-        if (verbose)
-            rsr_set_progress_callback(ctxs[size_t(i)], [](int done, int total, void*) { fprintf(stderr, "%.2f%%\n", total ? 100.f * float(done) / float(total) : 100.f); }, nullptr);
+        // the reference prints one line per tile, "%.2f%%" of (yi * xtiles + xi) / (ytiles * xtiles) (realsr.cpp:481): the same lines
+        // here, one per tile of every batch (a batch of tiles runs at once, so they arrive in bursts)
+        rsr_set_progress_callback(ctxs[size_t(i)], [](int done, int total, void*) { fprintf(stderr, "%.2f%%\n", total ? 100.f * float(done - 1) / float(total) : 0.f); }, nullptr);
         realsr.push_back(std::move(r));
     }
     // one image, several GPUs: every GPU takes a share of the tile rows

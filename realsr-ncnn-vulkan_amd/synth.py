@@ -156,7 +156,7 @@ def write_param(path):
 # --------------------------------------------------------------------------------------------
 # weights
 # --------------------------------------------------------------------------------------------
-def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.12, bias_std=0.02, round_fp16=True):
+def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.12, bias_std=0.02, round_fp16=True, hot=1.0):
     """Seeded synthetic weights, rounded to fp16-representable fp32.
 
     He-normal (fan_in, leaky slope 0.2) scaled by `rdb_gain` inside the dense blocks (ESRGAN initialises
@@ -166,6 +166,10 @@ def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.1
     `trunk_gain` to bring it back next to `fea`).  `last_gain` sizes conv_last so the output is ~0.55 +- 0.2 and
     over/undershoots [0,1] on a few % of the pixels: the +-1 uint8 parity check is then sensitive to every layer
     and exercises both clamps.  conv_last gets a bias of 0.5.
+
+    `hot` (weight-statistics headroom, tests/test_gpu_round2.py): conv_first is multiplied by it and conv_last divided by it -- every
+    feature map in between (the network is positively homogeneous up to its biases) is `hot` times larger, the output is not.
+    hot = 256 puts the trunk activations at ~1e3..1e4 of fp16's 65,504; hot = 8192 overflows fp16 storage.
     """
     rng = np.random.default_rng(seed)
     ws = []
@@ -180,7 +184,10 @@ def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.1
             gain = last_gain
         w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * np.float32(he * gain)
         b = rng.standard_normal(cout).astype(np.float32) * np.float32(bias_std)
+        if i == 0:
+            w, b = w * np.float32(hot), b * np.float32(hot)
         if i == len(specs) - 1:
+            w = w / np.float32(hot)
             b = b + np.float32(0.5)
         if round_fp16:  # False: full fp32 weights (a raw-fp32 x4.bin whose values the fp16 packer has to round)
             w = w.astype(np.float16).astype(np.float32)

@@ -217,6 +217,10 @@ def test_cli_directory_run_matches_library(tmp_path, model_dir):
     assert r.returncode == 0, r.stderr
     assert "both a.ppm and a.png output a.png" in r.stderr or "both a.png and a.ppm" in r.stderr
     assert sorted(os.listdir(outd)) == ["a.png", "a.ppm.png", "b.png"]
+    # the reference's progress lines, one per tile: "%.2f%%" of (yi * xtiles + xi) / (ytiles * xtiles) (realsr.cpp:481) -- a.png is
+    # 40x30 at tile 32 = 2 x 1 tiles -> 0.00% and 50.00%; b.png 33x21 = 2 x 1; a.ppm 24x24 = 1 tile
+    lines = r.stderr.splitlines()
+    assert lines.count("0.00%") == 3 and lines.count("50.00%") == 2, r.stderr
     sr = R.RealSR(0)
     sr.load(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
     sr.tilesize = 32

@@ -388,6 +388,41 @@ def test_raw_fp32_bin_with_unrepresentable_weights(tmp_path):
 
 
 # ---- memory policy: the tile batch follows the memory that is really free ---------------------------------------------
+def test_weight_statistics_headroom_hot_model(tmp_path):
+    """The real models-DF2K / DF2K_JPEG blobs are absent (/root/reference/.MISSING_LARGE_BLOBS), so what their statistics could do
+    to an fp16-storage engine is shown as headroom: a second synthetic model (seed 44) whose conv_first is 32 x larger and conv_last
+    32 x smaller -- every feature map in between is 32 x the stand-in's: trunk activations peak at ~6e3 (asserted >= 1e3, a tenth of
+    fp16's 65,504) -- and whose output saturates on >= 5 % of the pixels (both clamps of realsr.cpp:804,820-831 busy).  BASELINE C1
+    (256x256, tile 128) and one C2 tile (200x200 -> a 220x220 padded tile) must still be within +-1 of the oracle, whose
+    intermediates are fp32.  (Past 65,504 the model is refused by tools/check_real_model.py: tests/test_model_io.py.)"""
+    import importlib.util
+    d = synth.make_model_dir(str(tmp_path), "models-hot32", 44, hot=32.0, last_gain=0.15)
+    pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+    net = oracle.OracleNet(pp, bp)
+    spec = importlib.util.spec_from_file_location("check_real_model", os.path.join(ROOT, "tools", "check_real_model.py"))
+    crm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(crm)
+    probe = synth.make_image(1234, 64, 64)
+    tile = np.pad(probe, ((10, 10), (10, 10), (0, 0)), mode="reflect")[:, :, :3].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+    peaks, _ = crm.activation_ranges(net, np.ascontiguousarray(tile))
+    top = max(v for _, v in peaks)
+    assert 1e3 <= top < 65504, top
+    s = R.RealSR(0)
+    s.load(pp, bp)
+    try:
+        for name, img, T in (("C1", synth.make_image(1234, 256, 256), 128), ("one C2 tile", synth.make_image(1235, 200, 200), 200)):
+            s.tilesize = T
+            got = s.process(img)
+            ref = net.process(img, T)
+            dd = np.abs(got.astype(int) - ref.astype(int))
+            sat = float(((ref == 0) | (ref == 255)).mean())
+            print("hot model (trunk peak %.0f), %s: max |diff| %d, %.2f %% of the bytes differ, %.1f %% of the output saturated" % (top, name, dd.max(), 100 * (dd > 0).mean(), 100 * sat))
+            assert dd.max() <= 1, name
+            assert sat >= 0.05, (name, sat)
+    finally:
+        s.close()
+
+
 def test_workspace_budget_follows_free_memory(paths):
     """The reference bounds device memory through the tile size (main.cpp:761-774); here all tiles of an image form one batch
     whose workspace (17.6 GB for a 1080p frame at tile 200) must fit.  With all but ~8 GB of the device taken by somebody else
@@ -639,6 +674,80 @@ def test_tile_ranges_under_tta_and_rgba(paths):
     finally:
         a.close()
         b.close()
+
+
+def test_group_of_eight_under_concurrent_callers_and_a_failing_member(paths):
+    """First contact with an 8-GPU node, rehearsed on one device: rsr_process_group over EIGHT contexts (all on device 0:
+    rsr_create_group itself refuses duplicate ids) from FOUR caller threads at once -- 28 shares in flight on the process-wide worker
+    pool (grown on demand), two lanes per context (callers wait for lanes), different image sizes per caller (the reference's proc
+    threads share one RealSR per GPU the same way, main.cpp:811-828).  Every frame must equal the single-context bytes.  Then one
+    member refuses every workspace (test hook ws_fail_above_mb = 0): the call reports RSR_E_NOMEM naming the share, the other
+    members' shares complete, nobody hangs, and the group works again once the member recovers."""
+    srs = []
+    try:
+        for _ in range(8):
+            s = R.RealSR(0)
+            s.load(*paths)
+            s.tilesize = 32
+            s.set_option("max_lanes", 2)
+            s.set_option("max_workspace_mb", 2048)
+            srs.append(s)
+        imgs = [synth.make_image(500 + i, w, h) for i, (w, h) in enumerate([(200, 130), (90, 260), (257, 65), (128, 128)])]
+        want = [srs[0].process(im) for im in imgs]
+        bad = []
+
+        def caller(k):
+            try:
+                for _ in range(3):
+                    if not (R.process_group(srs, imgs[k]) == want[k]).all():
+                        bad.append((k, "bytes differ"))
+            except Exception as e:  # noqa: BLE001
+                bad.append((k, repr(e)))
+
+        ths = [threading.Thread(target=caller, args=(k,)) for k in range(4)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(300)
+        assert not any(t.is_alive() for t in ths), "a group call hangs"
+        assert not bad, bad
+        assert srs[0].get_stat("pool_workers") >= 7
+        srs[5].set_option("ws_fail_above_mb", 0)
+        with pytest.raises(R.RealSRError) as e:
+            R.process_group(srs, imgs[0])
+        assert e.value.code == R.RSR_E_NOMEM and "gpu share 5" in str(e.value), str(e.value)
+        srs[5].set_option("ws_fail_above_mb", -1)
+        for t in [threading.Thread(target=caller, args=(k,)) for k in range(4)]:
+            t.start()
+            t.join(300)
+        assert not bad, bad
+    finally:
+        for s in srs:
+            s.close()
+
+
+def test_group_share_runs_inline_when_no_worker_thread_can_be_started(paths):
+    """ADVICE r04: std::thread creation failing inside rsr_process_group (thread limit, no memory) must neither throw across the C
+    boundary nor leave a queued share without anybody to run it: the share runs on the calling thread.  Fresh process (an empty pool),
+    thread creation refused through the RSR_POOL_NO_THREADS test hook."""
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['RSR_POOL_NO_THREADS'] = '1'\n"
+        "import realsr_ncnn_vulkan_amd as R\n"
+        "from realsr_ncnn_vulkan_amd import synth\n"
+        "srs = []\n"
+        "for _ in range(3):\n"
+        "    s = R.RealSR(0); s.load(%r, %r); s.tilesize = 32; srs.append(s)\n"
+        "img = synth.make_image(9, 120, 70)\n"
+        "want = srs[0].process(img)\n"
+        "got = R.process_group(srs, img)\n"
+        "assert (got == want).all()\n"
+        "print('inline', int(srs[0].get_stat('pool_inline_runs')), 'workers', int(srs[0].get_stat('pool_workers')))\n"
+    ) % (ROOT, paths[0], paths[1])
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert "inline 2 workers 0" in r.stdout, r.stdout
 
 
 def test_create_group(paths, monkeypatch):

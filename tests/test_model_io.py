@@ -228,6 +228,23 @@ def test_real_model_harness_skips_without_a_blob_and_runs_host_checks(model_dir,
     assert 1.0 < max(v for _, v in rep["activation_peaks"]) < 65504
 
 
+def test_real_model_harness_refuses_weights_that_overflow_fp16(tmp_path):
+    """Weight statistics nobody has seen (the real x4.bin blobs are absent): the engine -- like the reference's Vulkan path,
+    realsr.cpp:44-46 -- STORES every feature map as fp16.  The network is positively homogeneous up to its biases, so fp16's
+    relative precision does not care about the scale of the activations (the hot = 32 model of tests/test_gpu_round2.py holds +-1
+    with trunk peaks of ~6e3) -- until a value passes 65,504.  A model whose trunk does (synth hot = 512: 194 x 512 = 9.9e4) must
+    be refused LOUDLY by tools/check_real_model.py's range guard, which is the one thing a range can tell; precision itself is
+    measured directly by the harness's GPU legs (pre-quantise error, C1 +-1)."""
+    import subprocess
+    import sys
+    from realsr_ncnn_vulkan_amd import synth
+    d = synth.make_model_dir(str(tmp_path), "models-hot512", 44, hot=512.0, last_gain=0.15)
+    tool = os.path.join(ROOT, "tools", "check_real_model.py")
+    r = subprocess.run([sys.executable, tool, d, "--no-gpu", "--range-tile", "48"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "OVERFLOWS fp16 storage" in r.stdout and "RESULT: FAILED" in r.stdout, r.stdout
+
+
 def test_flow_hook_generator_schedules_every_piece_once(tmp_path):
     """tools/gen_flow_hooks.py (run by the csrc Makefile): the deferred drain of one block = 4 rows x (8 pair conversions + 2 plane
     stores) = 40 pieces, each behind exactly one MFMA cell, a row's stores behind its conversions, every third cell by default;

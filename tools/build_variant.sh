@@ -1,5 +1,6 @@
 #!/bin/bash
-# Build an experimental variant of librealsr_hip.so:  tools/build_variant.sh NAME FILE "-DRSR_FLOW_TRACE ..."
+# Build an experimental variant of librealsr_hip.so:  tools/build_variant.sh NAME FILE "-DRSR_EXPERIMENT -DRSR_FLOW_TRACE ..."
+# (-DRSR_EXPERIMENT admits the instrumented / ablation code paths that the product build compiles out: conv_flow.hip RSR_ABL)
 # FILE = kernels | conv_flow.  -> realsr-ncnn-vulkan_amd/lib/exp/NAME.so   (load with RSR_LIB=<path>; lib/ is git-ignored
 # but travels to the GPU box)
 set -e

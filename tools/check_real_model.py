@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--no-gpu", action="store_true", help="host-only checks (encoding, graph, pack, activation ranges)")
     ap.add_argument("--no-bench", action="store_true")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--range-tile", type=int, default=148, help="edge of the padded tile the fp32 activation-range walk runs on (148 = C1's tiles)")
     args = ap.parse_args()
     if not args.no_gpu:
         # PyTorch's bundled HIP runtime has to be the first one in the process (realsr-ncnn-vulkan_amd/__init__.py: lib()); an
@@ -209,7 +210,8 @@ def main():
     from realsr_ncnn_vulkan_amd import synth
     img = synth.make_image(1234, 256, 256)
     big = np.pad(img, ((10, 10), (10, 10), (0, 0)), mode="reflect")
-    tile = big[:148, :148, :3].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+    rt = max(16, min(int(args.range_tile), 276))
+    tile = big[:rt, :rt, :3].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
     t = time.time()
     peaks, walked = activation_ranges(net, tile)
     graph_err = float(np.abs(walked - net.forward(np.ascontiguousarray(tile))).max())  # the walk above against the oracle's own DAG interpreter
@@ -219,7 +221,7 @@ def main():
         ok = False
     worst = max(peaks, key=lambda kv: kv[1])
     rep["activation_peaks"] = peaks
-    print("  fp32 activation range over a 148x148 tile (%.1f s): largest |value| %.4g at %s; fp16 max is %.0f" % (time.time() - t, worst[1], worst[0], FP16_MAX))
+    print("  fp32 activation range over a %dx%d tile (%.1f s): largest |value| %.4g at %s; fp16 max is %.0f" % (rt, rt, time.time() - t, worst[1], worst[0], FP16_MAX))
     for name, v in peaks:
         if v > FP16_MAX / 16:
             print("    %-22s %.4g%s" % (name, v, "   <-- OVERFLOWS fp16 storage" if v > FP16_MAX else "   (within 16x of the fp16 limit)"))

@@ -1,6 +1,6 @@
 """Where does a conv launch spend its time OUTSIDE the steady state?  Per-workgroup s_memtime stamps (100 MHz REFCLK, 10 ns) at
 kernel entry, at the first half-stage barrier (weights + first patch in LDS) and at exit, for all 256 workgroups of one launch.
-Needs a -DRSR_FLOW_LIFE build:   tools/build_variant.sh life conv_flow -DRSR_FLOW_LIFE
+Needs a -DRSR_FLOW_LIFE build:   tools/build_variant.sh life conv_flow "-DRSR_EXPERIMENT -DRSR_FLOW_LIFE"
                                  RSR_LIB=realsr-ncnn-vulkan_amd/lib/exp/life.so python tools/flow_life.py
 Reports, per conv class: launch span (first entry -> last exit), entry skew, PROLOGUE (entry -> first half-stage ready) and exit
 skew (first exit -> last exit: the tail in which workgroups idle), next to the HIP-event time of the same launch."""

@@ -1,5 +1,5 @@
-"""Per-half-stage barrier stamps of workgroup 0 / MFMA wave 0 of conv3x3_flow (needs a -DRSR_FLOW_TRACE build:
-tools/build_variant.sh trace conv_flow -DRSR_FLOW_TRACE; RSR_LIB=.../lib/exp/trace.so python tools/flow_trace.py)."""
+"""Per-half-stage barrier stamps of workgroup 0 / MFMA wave 0 of conv3x3_flow (needs a -DRSR_EXPERIMENT -DRSR_FLOW_TRACE build:
+tools/build_variant.sh trace conv_flow "-DRSR_EXPERIMENT -DRSR_FLOW_TRACE"; RSR_LIB=.../lib/exp/trace.so python tools/flow_trace.py)."""
 import os
 import sys
 

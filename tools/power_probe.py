@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Frame time, socket power and sclk for ablation variants of the C2 frame (GPU box):  python tools/power_probe.py "dbg=0;dbg=1;..." """
+"""Frame time, socket power and sclk for ablation variants of the C2 frame (GPU box):  python tools/power_probe.py "dbg=0;dbg=1;..."
+The ablation bits 1 / 4 / 64 / 128 exist only in an experiment build of conv_flow.hip (round 5: compiled out of the product):
+    tools/build_variant.sh abl conv_flow -DRSR_EXPERIMENT;  RSR_LIB=realsr-ncnn-vulkan_amd/lib/exp/abl.so python tools/power_probe.py ..."""
 import os, subprocess, sys, time, re, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -9,7 +9,7 @@
 //
 //   * K is walked in units of ONE 16-channel plane (a "half-stage": 36 MFMAs per 32 output channels).  A half-stage
 //     is a 20-KB patch + a 9-KB (x NT) weight image, so 6 (NT=1) / 4 (NT=2) patches and 3 weight images ride in a
-//     ring next to a dedicated transpose scratch: 5 / 3 half-stages of look-ahead instead of 2 / 1 stages.
+//     ring: 5 / 3 half-stages of look-ahead instead of 2 / 1 stages.
 //   * activations live in HBM as 16-channel planes [H][W][16] fp16 (32 B per pixel), so every LDS-DMA piece and
 //     every epilogue store is 1 KiB of whole cache lines; one v_mfma_f32_32x32x16_f16 consumes exactly one plane.
 //   * the MFMA waves never drain: operand fragments are reloaded IN PLACE, one (dx) step ahead, across half-stage
@@ -26,6 +26,12 @@
 // an MFMA result are runs of 8 consecutive output channels: a lane's 16 bytes of a plane row go to memory as they are (one
 // buffer_store_b128 per plane), the 4 ds_write_b64 + 2 ds_read_b128 per row and their waits are gone, and the deferred drain
 // (40 pieces instead of 60) rides behind every THIRD MFMA cell: -1.3 % frame time (profiles/r04_ab_epilogue.txt).
+//
+// Round 5: FOLDED blocks (kernels.h kFoldBit) -- a tile's last block column, when only 1..14 pixels wide (420 = 13 x 32 + 4), runs as one
+// 16 x 32 block per TWO block rows: strip 1 in patch columns / lanes 0..15, strip 2 (16 rows further down) in 16..31.  The matrix loop
+// is untouched; the loaders' gather (block_offsets) and the epilogue's scatter (make_out, store3) are what know.  The experiment
+// scaffolding of rounds 2-4 (ablation bits, s_memtime instrumentation, the Winograd instruction-mix study) now compiles only with
+// -DRSR_EXPERIMENT, and the LDS scratch the round 1-3 epilogue transposed through is gone from the LDS map.
 //
 // Round 3: weight images LDS-RESIDENT for the whole launch where they fit (WRES: every conv but the 192 -> 64
 // ones), MFMA waves SKIP blocks whose four rows lie below the tile or inside the frame of output pixels nothing kept depends on

@@ -282,7 +282,8 @@ static int tail_margin(int crop4, int which) // which: 0 conv_last, 1 HRconv, 2 
 // the 140-wide edge tiles of C2 4 columns + 7 folded items instead of 5 x 14 (-10 %).  Tile geometry: realsr.cpp:170-181,246-249.
 // The kernel decides "these four rows need no matrix work" (wave_is_dead) from a folded block's FIRST strip alone; that is exact for
 // rows below the tile and for the bottom margin, and it would be wrong where the first strip lies in the TOP margin and the second
-// does not -- so pairs that start above `mtop` (the largest margin any conv of this level is launched with) stay plain blocks.
+// does not -- so block rows that start above `mtop` (the largest margin any conv of this level is launched with) stay plain blocks and
+// the pairing begins below them.
 void append_block_items(std::vector<WorkItem>& out, int slot, int H, int W, int m, int mtop, int p0, int p1, int p2, bool fold)
 {
     const int rem = W % kBlkW;
@@ -296,17 +297,16 @@ void append_block_items(std::vector<WorkItem>& out, int slot, int H, int W, int 
             out.push_back(WorkItem{slot, y0, x0, H, W, p0, p1, p2});
         }
     };
-    for (int y0 = 0; y0 < H; y0 += 2 * kBlkH) // pairs of block rows
+    // block rows above the first one that starts at or below `mtop` stay plain; pairs are counted from there
+    const int first_pair = fold_last ? std::min(H, (mtop + kBlkH - 1) / kBlkH * kBlkH) : H;
+    for (int y0 = 0; y0 < first_pair; y0 += kBlkH) plain_row(y0, 0, W);
+    for (int y0 = first_pair; y0 < H; y0 += 2 * kBlkH) // pairs of block rows
     {
         const bool has2 = y0 + kBlkH < H;
-        const bool fold_pair = fold_last && y0 >= mtop;
-        plain_row(y0, 0, fold_pair ? wfull : W);
-        if (has2) plain_row(y0 + kBlkH, 0, fold_pair ? wfull : W);
-        if (fold_pair)
-        {
-            const bool dead = (row_skipped(y0) && (!has2 || row_skipped(y0 + kBlkH))) || wfull >= W - m;
-            if (!dead) out.push_back(WorkItem{slot, y0, wfull | kFoldBit, H, W, p0, p1, p2});
-        }
+        plain_row(y0, 0, wfull);
+        if (has2) plain_row(y0 + kBlkH, 0, wfull);
+        const bool dead = (row_skipped(y0) && (!has2 || row_skipped(y0 + kBlkH))) || wfull >= W - m;
+        if (!dead) out.push_back(WorkItem{slot, y0, wfull | kFoldBit, H, W, p0, p1, p2});
     }
 }
 

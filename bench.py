@@ -557,8 +557,9 @@ def main():
                 # +1.9 % at the LR level (32-pixel MFMA rows: 220 -> 224 columns; the 140-wide edge tiles' last 12 columns run as folded
                 # blocks since round 5: 144 instead of 160) -- executed_flop() is the model, PMC SQ_INSTS_VALU_MFMA_MOPS_F16 the measurement
                 "whole_path_frac_of_peak_executed": round(executed_flop(W_IN, H_IN, TILE, PREPAD) * args.steps / dt / 1e12 / PEAK_F16_TFLOPS, 4),
-                "frac_of_peak_caveat": "one binary measured 88.7-93.9 ms on five boards of round 3; the round-4 binary 87.5-93.8 ms on ten (38.9-41.7 % whole path): the boards "
-                                       "differ in the clock their power management grants under the 1,400 W cap (1,531-1,656 MHz seen); a single run is one board's number, not a floor",
+                "frac_of_peak_caveat": "one binary measured 88.7-93.9 ms on five boards of round 3, the round-4 binary 87.5-93.8 ms on ten, the round-5 code 86.1-90.7 ms on four "
+                                       "(41.2-42.4 % whole path in its three bench lines): the boards differ in the clock their power management grants under the 1,400 W cap "
+                                       "(1,531-1,656 MHz seen); a single run is one board's number, not a floor",
                 "checksum": checksum,
             },
         }
@@ -651,7 +652,7 @@ def main():
                           "`value` / `ms_per_step` come from the first, un-instrumented pass" % steps,
                 "consistency": {"dominant_kernel_ms_per_step": round(ring_ms / steps, 3), "ms_per_step_profiled": round(dt_prof / steps * 1e3, 3),
                                 "holds": bool(ring_ms / steps <= dt_prof / steps * 1e3)},
-                "note": "the board sits at its 1400 W cap during this workload (profiles/r04_power_clock.txt: 1400 W mean, sclk ~1.65 GHz of 2.4 over the timed region): "
+                "note": "the board sits at its 1400 W cap during this workload (profiles/r05_power_clock.txt: 1400 W mean, sclk ~1.63 GHz of 2.4 over the timed region): "
                         "at that clock the MFMA peak is ~1.7 PFLOP/s; fed entirely from the L2 the same kernels reach 45-51 % of 2.5 PF (profiles/r04_l2_bound.txt)",
             }
             try:

@@ -240,6 +240,37 @@ def test_c5_tta_against_oracle():
     print("C5 (models-DF2K_JPEG, TTA): %d tiles %s in full within +-1 of the live oracle, %.2f %% of the bytes differ" % (n, tiles or "(all)", 100 * frac))
 
 
+def test_baseline_tiles_against_an_independent_pytorch_graph(sr, weights):
+    """A second checker that shares NOTHING with oracle/realsr_oracle.c: the canonical ESRGAN RRDBNet(3, 3, 64, 23, gc = 32) assembled
+    from torch.nn.functional (tests/torch_ref.py: conv2d / leaky_relu 0.2 / cat / nearest x2, fp32 on the CPU), fed with the seeded
+    weights as synth.make_weights() produces them (not as any .bin reader parsed them) and with tiles cut by numpy (reflect-101 halo
+    of 10, realsr.cpp:613; crop 40, v * 255 + 0.5, truncate, clamp, realsr.cpp:804,820-831).  Tiles of the C2 frame -- the first
+    (220x220), a 220x100, the 140x100 corner -- and the 260x180 corner of the C3 frame (folded last block column) must be within +-1
+    uint8 of it (~35 s of PyTorch-CPU time; a first run with six tiles incl. an interior C2 tile and a 420x180 C3 tile: profiles/r05_gpu_tests.txt): the same bar as against the oracle, by an independent route (SURVEY 8(c):
+    "independent cross-check available in-container: PyTorch CPU")."""
+    import torch_ref
+    wl = [(np.ascontiguousarray(W, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)) for W, b in weights]
+    try:
+        for name, iseed, w, h, T, tiles in (("C2", 1235, 1920, 1080, 200, [(0, 0), (4, 5), (9, 5)]),
+                                            ("C3", 1236, 3840, 2160, 400, [(9, 5)])):
+            sr.tilesize = T
+            img = synth.make_image(iseed, w, h)
+            out = sr.process(img)
+            worst, ndiff, total = 0, 0, 0
+            for xi, yi in tiles:
+                x0, y0 = xi * T, yi * T
+                tw, th = min(x0 + T, w) - x0, min(y0 + T, h) - y0
+                ref = torch_ref.net_forward_np(wl, oracle_pool.padded_tile(img, x0, y0, tw, th))
+                ref8 = quantise(ref)
+                got = out[4 * y0:4 * (y0 + th), 4 * x0:4 * (x0 + tw)].astype(int)
+                d = np.abs(got - ref8)
+                assert d.max() <= 1, "%s tile (%d,%d): max diff %d vs the PyTorch graph" % (name, xi, yi, d.max())
+                worst, ndiff, total = max(worst, int(d.max())), ndiff + int((d > 0).sum()), total + d.size
+            print("%s: %d tiles %s within +-1 of the independent PyTorch graph, %.2f %% of the bytes differ" % (name, len(tiles), tiles, 100.0 * ndiff / total))
+    finally:
+        sr.tilesize = 200
+
+
 def test_engine_options_do_not_change_the_bytes(paths, sr):
     """Scheduling / staging knobs (include/realsr_hip.h: rsr_set_option) are implementation details: tail launch groups,
     work-item order, one lane, single-threaded staging copies, small download chunks, no dead-output elimination, rows below

@@ -228,6 +228,47 @@ def test_real_model_harness_skips_without_a_blob_and_runs_host_checks(model_dir,
     assert 1.0 < max(v for _, v in rep["activation_peaks"]) < 65504
 
 
+def test_header_is_plain_c_and_a_c_host_links_against_the_abi(tmp_path):
+    """The drop-in boundary is a C ABI (extern "C", plain pointers and sizes, no C++ / torch types in the signatures): include/realsr_hip.h
+    must compile as C99 with -pedantic, and a host written in C must link against librealsr_hip.so and reach the host-only entry points
+    without a GPU -- rsr_version, rsr_tile_partition (C2's 60 tiles over 8 shares), rsr_model_info on a generated model directory, and
+    rsr_create failing LOUDLY with an error code and a message when there is no gfx950 device (no CPU fallback: realsr.cpp:147-151's
+    -g -1 path exists only as the test oracle)."""
+    import subprocess
+    import sys
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "realsr_hip.h"
+int main(void)
+{
+    int b[9], n, i, rc;
+    rsr_ctx* ctx = NULL;
+    printf("version %s\n", rsr_version());
+    n = rsr_tile_partition(1920, 1080, 200, 10, 8, b);
+    printf("shares %d:", n);
+    for (i = 0; i <= n; i++) printf(" %d", b[i]);
+    printf("\n");
+    rc = rsr_create(&ctx, 0, 0, 1);
+    printf("create rc %d ctx %s msg [%s]\n", rc, ctx ? "set" : "null", rc ? rsr_last_error(NULL) : "");
+    if (rc == 0) rsr_destroy(ctx);
+    return (n == 8 && b[0] == 0 && b[8] == 60) ? 0 : 1;
+}
+''')
+    lib = os.path.join(ROOT, "realsr-ncnn-vulkan_amd", "lib")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "realsr_hip.h")])
+    exe = str(tmp_path / "host")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-o", exe, str(src), "-L", lib, "-lrealsr_hip", "-Wl,-rpath," + lib])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "version " in r.stdout and "shares 8: 0 " in r.stdout
+    import torch
+    if not torch.cuda.is_available():  # the GPU-less container: the C host sees a loud failure, not a fallback
+        assert "create rc -" in r.stdout and "ctx null" in r.stdout and "msg []" not in r.stdout, r.stdout
+
+
 def test_real_model_harness_refuses_weights_that_overflow_fp16(tmp_path):
     """Weight statistics nobody has seen (the real x4.bin blobs are absent): the engine -- like the reference's Vulkan path,
     realsr.cpp:44-46 -- STORES every feature map as fp16.  The network is positively homogeneous up to its biases, so fp16's

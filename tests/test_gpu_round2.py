@@ -240,6 +240,37 @@ def test_c5_tta_against_oracle():
     print("C5 (models-DF2K_JPEG, TTA): %d tiles %s in full within +-1 of the live oracle, %.2f %% of the bytes differ" % (n, tiles or "(all)", 100 * frac))
 
 
+def test_rgba_frame_at_baseline_size(sr, paths):
+    """no BASELINE config has an alpha channel.  The C2 frame with one added: 1920x1080 RGBA at tile 200 through the
+    alpha path (alpha kept un-normalised next to the RGB planes, ncnn-flavoured bicubic x4 of every tile's UN-PADDED alpha rectangle in
+    postproc_tiles -- realsr_preproc.comp:79-88, realsr.cpp:128-140,431-442, realsr_postproc.comp:58-61 -- so the planar conv_last /
+    postproc launch instead of the fused uint8 epilogue).  The RGB channels must satisfy the committed C2 oracle samples (all 60
+    tiles, +-1: the alpha channel must not disturb them), and the alpha channel the oracle's bicubic, tile by tile, +0.5, saturate
+    (+-1; every tile shape: 200x200, 200x80, 120x200, 120x80)."""
+    sr.tilesize = 200
+    rgb = synth.make_image(1235, 1920, 1080)
+    yy, xx = np.mgrid[0:1080, 0:1920]
+    alpha = ((np.sin(xx / 37.0) * np.cos(yy / 23.0) * 0.5 + 0.5) * 255).astype(np.uint8)
+    alpha[300:420, 500:900] = 0      # hard edges, also across tile borders (x = 600, 800; y = 400)
+    alpha[390:410, 100:1800] = 255
+    img = np.concatenate([rgb, alpha[:, :, None]], axis=2)
+    out = sr.process(img)
+    assert out.shape == (4320, 7680, 4)
+    n, frac = oracle_pool.check_frame_golden(out, "c2", rgb, paths[1], 200)
+    assert n == 60
+    worst, ndiff, total = 0, 0, 0
+    for y0 in range(0, 1080, 200):
+        for x0 in range(0, 1920, 200):
+            th, tw = min(y0 + 200, 1080) - y0, min(x0 + 200, 1920) - x0
+            ref = oracle.bicubic(alpha[y0:y0 + th, x0:x0 + tw].astype(np.float32), 4 * th, 4 * tw)
+            ref8 = np.clip((ref + 0.5).astype(np.int32), 0, 255)
+            d = np.abs(out[4 * y0:4 * (y0 + th), 4 * x0:4 * (x0 + tw), 3].astype(int) - ref8)
+            assert d.max() <= 1, "alpha of the tile at (%d,%d): max diff %d" % (x0, y0, d.max())
+            worst, ndiff, total = max(worst, int(d.max())), ndiff + int((d > 0).sum()), total + d.size
+    print("RGBA 1080p: RGB 60 of 60 tiles within +-1 of the golden C2 samples (%.2f %% differ); alpha 60 of 60 tiles within +-1 of the oracle's bicubic (max %d, %.3f %% differ)" % (
+        100 * frac, worst, 100.0 * ndiff / total))
+
+
 def test_baseline_tiles_against_an_independent_pytorch_graph(sr, weights):
     """A second checker that shares NOTHING with oracle/realsr_oracle.c: the canonical ESRGAN RRDBNet(3, 3, 64, 23, gc = 32) assembled
     from torch.nn.functional (tests/torch_ref.py: conv2d / leaky_relu 0.2 / cat / nearest x2, fp32 on the CPU), fed with the seeded

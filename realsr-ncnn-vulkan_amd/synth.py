@@ -156,7 +156,7 @@ def write_param(path):
 # --------------------------------------------------------------------------------------------
 # weights
 # --------------------------------------------------------------------------------------------
-def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.12, bias_std=0.02, round_fp16=True, hot=1.0):
+def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.12, bias_std=0.02, round_fp16=True, hot=1.0, chan_sigma=0.0):
     """Seeded synthetic weights, rounded to fp16-representable fp32.
 
     He-normal (fan_in, leaky slope 0.2) scaled by `rdb_gain` inside the dense blocks (ESRGAN initialises
@@ -170,6 +170,10 @@ def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.1
     `hot` (weight-statistics headroom, tests/test_gpu_round2.py): conv_first is multiplied by it and conv_last divided by it -- every
     feature map in between (the network is positively homogeneous up to its biases) is `hot` times larger, the output is not.
     hot = 256 puts the trunk activations at ~1e3..1e4 of fp16's 65,504; hot = 8192 overflows fp16 storage.
+
+    `chan_sigma` > 0: every conv's OUTPUT channels get log-normal gains exp(sigma * N(0,1)), normalised to unit RMS per conv -- the
+    channel-to-channel spread trained ESRGAN weights show (a few loud channels, many quiet ones) instead of i.i.d. filters; sigma = 1
+    spreads the channel scales over ~50x.
     """
     rng = np.random.default_rng(seed)
     ws = []
@@ -184,6 +188,10 @@ def make_weights(seed, rdb_gain=0.6, io_gain=1.0, trunk_gain=0.02, last_gain=0.1
             gain = last_gain
         w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * np.float32(he * gain)
         b = rng.standard_normal(cout).astype(np.float32) * np.float32(bias_std)
+        if chan_sigma > 0 and i != len(specs) - 1:
+            g = np.exp(chan_sigma * rng.standard_normal(cout)).astype(np.float32)
+            g /= np.sqrt(np.mean(g * g))
+            w, b = w * g[:, None, None, None], b * g
         if i == 0:
             w, b = w * np.float32(hot), b * np.float32(hot)
         if i == len(specs) - 1:

@@ -485,6 +485,52 @@ def test_weight_statistics_headroom_hot_model(tmp_path):
         s.close()
 
 
+def test_weight_statistics_channel_spread_model(tmp_path):
+    """Trained ESRGAN weights are not i.i.d. filters: a few loud output channels, many quiet ones.  A third stand-in (seed 45, synth
+    chan_sigma = 1: log-normal per-output-channel gains, unit RMS per conv, ~50x between the loudest and the quietest channel of a conv;
+    trunk peaks ~7e2).  (1) With the base model's output swing (last_gain 0.12) BASELINE C1 holds +-1 against the oracle.  (2) With a
+    1.7x larger output swing (last_gain 0.2: fp32 output -0.56 .. 1.79) the fp16 STORAGE noise itself reaches one uint8 step (max
+    pre-quantise error 4.3e-3 vs 1 / 255 = 3.9e-3) and ONE byte of the 3.1 M of the C1 frame differs by 2 (measured, round 5) -- that
+    is the format the reference's Vulkan path shares (realsr.cpp:44-46), not this engine's arithmetic: on a tile of that model the
+    engine's deviation from the fp32 oracle must equal, statistically, that of a PyTorch emulation of fp16 storage / fp32 arithmetic
+    (tests/torch_ref.py rrdbnet_forward_fp16_storage: mean within 10 %, p99.9 within 25 %), and the engine must be CLOSER to that
+    emulation than either is to the oracle.  DESIGN.md section 3 states the bar accordingly."""
+    import torch_ref
+    img = synth.make_image(1234, 256, 256)
+    d = synth.make_model_dir(str(tmp_path), "models-spread", 45, chan_sigma=1.0, last_gain=0.12)
+    pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+    s = R.RealSR(0)
+    s.load(pp, bp)
+    try:
+        s.tilesize = 128
+        got = s.process(img)
+    finally:
+        s.close()
+    ref = oracle.OracleNet(pp, bp).process(img, 128)
+    dd = np.abs(got.astype(int) - ref.astype(int))
+    print("channel-spread model, C1: max |diff| %d, %.2f %% of the bytes differ" % (dd.max(), 100 * (dd > 0).mean()))
+    assert dd.max() <= 1
+    d = synth.make_model_dir(str(tmp_path), "models-spread-wide", 45, chan_sigma=1.0, last_gain=0.2)
+    pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+    net = oracle.OracleNet(pp, bp)
+    wl = [(c["weight"], c["bias"]) for c in (net.conv(i) for i in range(net.num_convs))]
+    tile = np.ascontiguousarray(oracle_pool.padded_tile(img, 0, 0, 128, 128))
+    a = net.forward(tile)
+    b = torch_ref.net_forward_fp16_storage_np(wl, tile)
+    s = R.RealSR(0)
+    s.load(pp, bp)
+    try:
+        c = s.net_forward(tile.astype(np.float16)).astype(np.float32)
+    finally:
+        s.close()
+    e_eng, e_emu, e_x = np.abs(c - a), np.abs(b - a), np.abs(c - b)
+    print("wide-swing spread model, one 148x148 tile: engine vs oracle mean %.3e p99.9 %.3e max %.3e | fp16-storage emulation vs oracle mean %.3e p99.9 %.3e max %.3e | "
+          "engine vs emulation mean %.3e" % (e_eng.mean(), np.quantile(e_eng, 0.999), e_eng.max(), e_emu.mean(), np.quantile(e_emu, 0.999), e_emu.max(), e_x.mean()))
+    assert abs(e_eng.mean() / e_emu.mean() - 1) < 0.10
+    assert abs(np.quantile(e_eng, 0.999) / np.quantile(e_emu, 0.999) - 1) < 0.25
+    assert e_x.mean() < e_eng.mean() and e_x.mean() < e_emu.mean()
+
+
 def test_workspace_budget_follows_free_memory(paths):
     """The reference bounds device memory through the tile size (main.cpp:761-774); here all tiles of an image form one batch
     whose workspace (17.6 GB for a 1080p frame at tile 200) must fit.  With all but ~8 GB of the device taken by somebody else

@@ -147,6 +147,25 @@ def gpu_checks(pp, bp, net, rep, bench):
     if not np.isfinite(got).all() or e.max() > 4e-3 or np.quantile(e, 0.999) > 2e-3:
         print("  FAIL: pre-quantise error outside the stated tolerance")
         ok = False
+    # Is that error the engine's arithmetic or the fp16 STORAGE format (which the reference's Vulkan path shares, realsr.cpp:44-46)?
+    # A PyTorch-CPU emulation of fp16 storage / fp32 arithmetic on the same tile must deviate from the fp32 oracle by the same amount.
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch_ref
+        wl = [(c["weight"], c["bias"]) for c in (net.conv(i) for i in range(net.num_convs))]
+        emu = torch_ref.net_forward_fp16_storage_np(wl, x.astype(np.float32))
+        ee, ex = np.abs(emu - ref), np.abs(got - emu)
+        rep["fp16_storage_emulation"] = {"emulation_vs_oracle_mean": float(ee.mean()), "emulation_vs_oracle_p99_9": float(np.quantile(ee, 0.999)), "emulation_vs_oracle_max": float(ee.max()),
+                                         "engine_vs_oracle_mean": float(e.mean()), "engine_vs_emulation_mean": float(ex.mean())}
+        print("  fp16-storage emulation (PyTorch CPU) vs oracle on that tile: max %.3e  p99.9 %.3e  mean %.3e;  engine vs oracle mean %.3e;  engine vs emulation mean %.3e" % (
+            ee.max(), np.quantile(ee, 0.999), ee.mean(), e.mean(), ex.mean()))
+        print("  headroom of the +-1 uint8 bar: one step (1/255 = 3.92e-3) / max pre-quantise error = %.2f (below ~1 single bytes may differ by 2 from the fp32 CPU path: the storage format, not a defect)" % (
+            (1.0 / 255.0) / max(float(e.max()), 1e-12)))
+        if abs(e.mean() / max(ee.mean(), 1e-12) - 1) > 0.15:
+            print("  FAIL: the engine's deviation from the oracle is not what fp16 storage alone explains (mean error differs from the emulation's by > 15 %)")
+            ok = False
+    except Exception as ex_:  # noqa: BLE001 -- a diagnostic, never the reason the harness dies
+        print("  (fp16-storage emulation skipped: %r)" % (ex_,))
     # C1: whole frame, tile 128, +-1 uint8
     sr.tilesize = 128
     t = time.time()

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Small images on one GPU (the reference's "-j 4:4:4 for many small images" mode, main.cpp:708-711,811-828, README.md:61):
+what do (a) several caller threads on one context, (b) several contexts (= compute streams + workspaces) on one GPU and
+(c) several images merged into ONE tile batch buy?  Device-resident images, 256x256 at tile 128 (4 tiles of 148x148).
+    python tools/small_image_probe.py [frames]"""
+import os, sys, time, threading
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import realsr_ncnn_vulkan_amd as R
+from realsr_ncnn_vulkan_amd import synth
+
+d = synth.make_model_dir(os.environ.get("RSR_MODELS", "/tmp/rsr_models"), "models-DF2K", 42)
+pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+FR = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+
+
+def mk(T=128, **opt):
+    s = R.RealSR(0); s.load(pp, bp); s.tilesize = T
+    for k, v in opt.items():
+        s.set_option(k, v)
+    return s
+
+
+def bench(ctxs, threads_per_ctx, w, h, frames, host=False):
+    """frames images of w x h in total, dealt to len(ctxs) * threads_per_ctx caller threads"""
+    img = synth.make_image(5, w, h)
+    nthr = len(ctxs) * threads_per_ctx
+    if host:
+        pin = R.PinnedArray((h, w, 3)); pin.array[:] = img
+        outs = [R.PinnedArray((h * 4, w * 4, 3)) for _ in range(nthr)]
+        call = lambda c, i: c.process(pin.array, out=outs[i].array, push_params=False)
+    else:
+        d_in = torch.from_numpy(img).cuda()
+        outs = [torch.empty((h * 4, w * 4, 3), dtype=torch.uint8, device="cuda") for _ in range(nthr)]
+        call = lambda c, i: c.process_device(d_in.data_ptr(), w, h, 3, outs[i].data_ptr())
+    for i in range(nthr):
+        call(ctxs[i % len(ctxs)], i)
+    torch.cuda.synchronize()
+    per = frames // nthr
+
+    def work(i):
+        c = ctxs[i % len(ctxs)]
+        for _ in range(per):
+            call(c, i)
+    t = time.time()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+    [x.start() for x in th]; [x.join() for x in th]
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    n = per * nthr
+    return dt / n * 1e3, 16.0 * w * h * n / dt / 1e6
+
+
+a = mk()
+print("256x256 tile 128, device-resident images, %d frames" % FR)
+for nthr in (1, 2, 4):
+    ms, mp = bench([a], nthr, 256, 256, FR)
+    print("  1 context x %d caller threads: %.2f ms per image, %.1f Mpix/s" % (nthr, ms, mp), flush=True)
+more = [mk() for _ in range(3)]
+for nc in (2, 4):
+    ms, mp = bench([a] + more[:nc - 1], 1, 256, 256, FR)
+    print("  %d contexts x 1 thread: %.2f ms per image, %.1f Mpix/s" % (nc, ms, mp), flush=True)
+ms, mp = bench([a] + more, 2, 256, 256, FR)
+print("  4 contexts x 2 threads: %.2f ms per image, %.1f Mpix/s" % (ms, mp), flush=True)
+for c in more:
+    c.close()
+print("merged batches (one image of the same tile count as k 256x256 images), 1 context x 1 thread:")
+for k, (w, h) in ((2, (512, 256)), (4, (512, 512)), (8, (1024, 512)), (16, (1024, 1024)), (32, (2048, 1024))):
+    ms, mp = bench([a], 1, w, h, max(4, FR // k))
+    print("  k=%2d (%dx%d, %d tiles): %.2f ms per batch = %.2f ms per 256x256 image, %.1f Mpix/s" % (k, w, h, 4 * k, ms, ms / k, mp), flush=True)
+print("host -> host (pinned), 256x256:")
+for nthr in (1, 2, 4):
+    ms, mp = bench([a], nthr, 256, 256, FR, host=True)
+    print("  1 context x %d caller threads: %.2f ms per image, %.1f Mpix/s" % (nthr, ms, mp), flush=True)
+a.close()

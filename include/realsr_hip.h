@@ -174,6 +174,10 @@ int rsr_postproc_tta(rsr_ctx* ctx, const uint16_t* const bottom[8], int w, int h
 /* in: planar fp16 [3][h][w] in [0,1]; out: planar fp16 [3][4h][4w].  Host pointers. */
 int rsr_net_forward(rsr_ctx* ctx, const uint16_t* in, int w, int h, uint16_t* out);
 
+/* The same with the network's result in fp32 (planar [3][4h][4w]), as conv_last leaves it in precise mode (option "precise" = 1;
+ * RSR_E_STATE otherwise): what the uint8 conversion sees there.  rsr_net_forward in precise mode returns this blob rounded to fp16. */
+int rsr_net_forward_f32(rsr_ctx* ctx, const uint16_t* in, int w, int h, float* out);
+
 /* One 3x3/s1/p1 convolution through the MFMA kernel with caller-supplied weights (layer-level parity;
  * the arithmetic ncnn::Convolution [+ Interp nearest x2 in front when upsample2x] performs for each
  * Convolution line of x4.param).  in: planar fp16 [cin][h][w]; weight: fp32 OIHW [cout][cin][3][3]
@@ -189,6 +193,14 @@ int rsr_conv3x3(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, int ups
  * res: planar fp16 [cout][h][w] or NULL; cout 32 or 64; no upsampling, no activation.  Host pointers. */
 int rsr_conv3x3_res(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, const float* weight, const float* bias, int cout,
                     float s1, int own_input_residual, const uint16_t* res, float s2, uint16_t* out);
+
+/* The same residual forms as the engine runs them in precise mode (option "precise"; 64 output channels): every tensor of the
+ * residual stream is hi + lo / 2048 in two fp16 blobs (lo = fp16((v - hi) * 2048), the rounding residue of hi = fp16(v)); the adds
+ * are done in fp32 and rounded once.  in_lo: lo of in[0:64] (own_input_residual only), res_lo: lo of res, out_lo: receives the lo of
+ * the result; any of the three may be NULL (= zero / not wanted).  Layouts as rsr_conv3x3_res. */
+int rsr_conv3x3_res_precise(rsr_ctx* ctx, const uint16_t* in, const uint16_t* in_lo, int cin, int h, int w, const float* weight,
+                            const float* bias, float s1, int own_input_residual, const uint16_t* res, const uint16_t* res_lo, float s2,
+                            uint16_t* out, uint16_t* out_lo);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct rsr_profile
@@ -232,6 +244,11 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "tail_group"        slots (tiles; x8 under TTA) per launch group of the 2x / 4x convs (default 0 = the whole batch at once).  Small
  *                       groups keep the 4x intermediates in the Infinity Cache between upconv2 -> HRconv -> conv_last; measured
  *                       worth <= 1.5 % of those launches on MI355X and a loss at the 2x level, hence off
+ *   "precise"           1: the 64-channel residual stream of the network is kept as TWO fp16 values per element (the fp16 the convs
+ *                       read + its rounding residue) and conv_last's fp32 result is converted to uint8 without an fp16 blob in
+ *                       between: half the distance to the reference's fp32 CPU path (realsr.cpp:525-838) that fp16 storage -- the
+ *                       reference's own GPU path, realsr.cpp:44-46, and this engine's default (0) -- has; costs ~8 % more workspace
+ *                       and the extra traffic of the lo planes in 93 of the 351 convolutions
  *   "bgr"               1: the caller's images are BGR(A) (the reference's Windows build: WIC decodes to BGR, realsr.cpp:188-206,
  *                       497-515, realsr_preproc.comp:17-21); the network always sees RGB.  Default 0 = RGB(A)
  *   "max_lanes"         rsr_process calls in flight per context (default 4); "chunk_mb": download chunk for pageable

@@ -26,6 +26,7 @@ EXPORTS = [
     "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_host_alloc", "rsr_host_free",
     "rsr_set_progress_callback", "rsr_conv3x3_res", "rsr_create_group", "rsr_group_transport", "rsr_process_rows",
     "rsr_process_group", "rsr_device_memory", "rsr_process_tiles", "rsr_tile_partition", "rsr_rccl_probe", "rsr_get_stat",
+    "rsr_net_forward_f32", "rsr_conv3x3_res_precise",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -99,6 +100,8 @@ def lib():
     L.rsr_net_forward.argtypes = [vp, vp, ip, ip, vp]
     L.rsr_conv3x3.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp]
     L.rsr_conv3x3_res.argtypes = [vp, vp, ip, ip, ip, vp, vp, ip, C.c_float, ip, vp, C.c_float, vp]
+    L.rsr_net_forward_f32.argtypes = [vp, vp, ip, ip, vp]
+    L.rsr_conv3x3_res_precise.argtypes = [vp, vp, vp, ip, ip, ip, vp, vp, C.c_float, ip, vp, vp, C.c_float, vp, vp]
     L.rsr_create_group.argtypes = [C.POINTER(vp), C.POINTER(ip), ip, ip, cp, cp]
     L.rsr_group_transport.restype = cp
     L.rsr_process_rows.argtypes = [vp, vp, ip, ip, ip, vp, ip, ip]
@@ -271,6 +274,29 @@ class RealSR:
         out = np.empty((3, 4 * h, 4 * w), dtype=np.float16)
         self._ck(self._L.rsr_net_forward(self._h, _p(x), w, h, _p(out)))
         return out
+
+    def net_forward_f32(self, x):
+        """x: float16 planar (3,h,w) -> float32 (3,4h,4w): conv_last's unrounded result (option "precise" = 1 only)."""
+        x = np.ascontiguousarray(x, dtype=np.float16)
+        _, h, w = x.shape
+        out = np.empty((3, 4 * h, 4 * w), dtype=np.float32)
+        self._ck(self._L.rsr_net_forward_f32(self._h, _p(x), w, h, _p(out)))
+        return out
+
+    def conv3x3_res_precise(self, x, weight, bias, s1, own_input_residual=False, x_lo=None, res=None, res_lo=None, s2=1.0, want_lo=True):
+        """rsr_conv3x3_res_precise: the residual forms on the hi + lo / 2048 stream; returns (hi, lo) float16 (lo None unless want_lo)."""
+        x = np.ascontiguousarray(x, dtype=np.float16)
+        weight = np.ascontiguousarray(weight, dtype=np.float32)
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+        cin, h, w = x.shape
+        assert weight.shape[0] == 64
+        f16 = lambda t: None if t is None else np.ascontiguousarray(t, dtype=np.float16)  # noqa: E731
+        x_lo, res, res_lo = f16(x_lo), f16(res), f16(res_lo)
+        out = np.empty((64, h, w), dtype=np.float16)
+        out_lo = np.empty((64, h, w), dtype=np.float16) if want_lo else None
+        self._ck(self._L.rsr_conv3x3_res_precise(self._h, _p(x), _p(x_lo), cin, h, w, _p(weight), _p(bias), float(s1),
+                                                 int(bool(own_input_residual)), _p(res), _p(res_lo), float(s2), _p(out), _p(out_lo)))
+        return out, out_lo
 
     def conv3x3(self, x, weight, bias, lrelu=False, upsample2x=False):
         x = np.ascontiguousarray(x, dtype=np.float16)

@@ -290,6 +290,12 @@ int rsr_net_forward(rsr_ctx* ctx, const uint16_t* in, int w, int h, uint16_t* ou
     return ctx->e.net_forward(in, w, h, out);
 }
 
+int rsr_net_forward_f32(rsr_ctx* ctx, const uint16_t* in, int w, int h, float* out)
+{
+    if (!ctx) return RSR_E_ARG;
+    return ctx->e.net_forward(in, w, h, nullptr, out);
+}
+
 int rsr_conv3x3(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, int upsample2x, const float* weight, const float* bias,
                 int cout, int lrelu, uint16_t* out)
 {
@@ -303,6 +309,14 @@ int rsr_conv3x3_res(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, con
     if (!ctx) return RSR_E_ARG;
     if (s1 == 0.f) return Engine::fail(RSR_E_ARG, "s1 must be non-zero");
     return ctx->e.conv_test(in, cin, h, w, 0, weight, bias, cout, 0, out, s1, own_input_residual, res, s2);
+}
+
+int rsr_conv3x3_res_precise(rsr_ctx* ctx, const uint16_t* in, const uint16_t* in_lo, int cin, int h, int w, const float* weight, const float* bias,
+                            float s1, int own_input_residual, const uint16_t* res, const uint16_t* res_lo, float s2, uint16_t* out, uint16_t* out_lo)
+{
+    if (!ctx) return RSR_E_ARG;
+    if (s1 == 0.f) return Engine::fail(RSR_E_ARG, "s1 must be non-zero");
+    return ctx->e.conv_test(in, cin, h, w, 0, weight, bias, 64, 0, out, s1, own_input_residual, res, s2, true, in_lo, res_lo, out_lo);
 }
 
 int rsr_set_profiling(rsr_ctx* ctx, int enable)
@@ -394,8 +408,10 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     }
     else if (k == "bgr")
         ctx->e.bgr = value != 0;
+    else if (k == "precise")
+        ctx->e.precise = value != 0; // plans are keyed by it (larger slots); the workspace grows on the next call
     else if (k == "flow_flags")
-        ctx->e.flow_flags = int(value);
+        ctx->e.flow_flags = int(value); // plans are keyed by bit 0 (it halves the largest tile the 32-bit plane offsets can address)
     else if (k == "max_lanes")
     {
         if (value < 1 || value > 64) return ctx->e.fail(RSR_E_ARG, "max_lanes out of range");

@@ -135,6 +135,15 @@ __device__ __forceinline__ char* uniform_ptr(const void* p)
 
 // EPI: 0 generic (conv_last: planar fp16 [3][H][W] output)      1 v = act(acc)  -> fp16 planes      3 conv_last with (dy, cout) in M
 //      2 v = s1*acc (the conv's own input rides in the accumulator as an identity tap) [, v = s2*v + r2] -> fp16 planes
+//      4 / 5 the PRECISE forms of 2 without / with the second residual (engine option "precise"; 64 output channels): the residual
+//        stream is kept as hi + lo / 2048 in two fp16 planes per 16 channels (kernels.h ConvArgs::precise) --
+//        v = s1*acc + lo1/2048 [, v = s2*v + r2 + lo2/2048] in fp32, then ONE rounding: hi = fp16(v) -> out16 (what the next convs
+//        read), lo = fp16((v - hi) * 2048) -> the output's lo planes.  The reference's GPU path rounds the trunk 92 times on its way
+//        through the 23 RRDBs (fp16 storage, realsr.cpp:44-46); this halves the engine's distance to the fp32 CPU path
+//        (realsr.cpp:525-838; profiles/r06_storage_emulation.txt).  Absent lo planes are read through a null buffer resource
+//        (zeros, no memory access) and written into one: the epilogue is branch-free.
+//      6 / 7 = 3 / 0 in precise mode: conv_last's fp32 result goes to the uint8 conversion (or a planar fp32 blob) without the fp16
+//        rounding of the reference's `output` blob in between.
 // NTW: n-tiles (32 output channels) per MFMA wave; the workgroup has 4*NT/NTW MFMA waves + 4 loader waves.
 // DEFER: double-buffered accumulators, block r drained underneath block r+1 (NT == 1 only).
 // WRES: the conv's weight images stay RESIDENT in LDS for the whole launch (loaded once per workgroup; slot = plane index, the
@@ -152,7 +161,13 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     constexpr int WB = C::WB;
     constexpr bool WDB = (NTW == 1); // double-buffered weight fragments (registers to spare with one n-tile per wave)
     static_assert(!DEFER || (NT == 1 && NTW == 1), "deferred epilogue needs the 256-VGPR budget of the 8-wave workgroup");
-    static_assert(EPI != 3 || (NT == 1 && NTW == 1 && !UPS && !DEFER && WRES), "conv_last's (dy, cout) layout: 32 rows, resident aux image");
+    constexpr bool LAST3 = (EPI == 3 || EPI == 6); // conv_last with (dy, cout) in M
+    constexpr bool LASTG = (EPI == 0 || EPI == 7); // conv_last through the generic path
+    constexpr bool OUT32 = (EPI == 6 || EPI == 7); // ... in precise mode: its fp32 result is what is converted to uint8 / stored (planar fp32)
+    static_assert(!LAST3 || (NT == 1 && NTW == 1 && !UPS && !DEFER && WRES), "conv_last's (dy, cout) layout: 32 rows, resident aux image");
+    static_assert((EPI != 4 && EPI != 5) || (NT == 2 && NTW == 1 && !UPS && !DEFER), "the precise residual epilogue exists for the 64-output-channel convs of the trunk");
+    constexpr bool RESID = (EPI == 2 || EPI == 4 || EPI == 5); // residual forms
+    constexpr bool PREC = (EPI == 4 || EPI == 5);              // ... with the hi + lo residual stream
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -166,7 +181,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     const int nst = a.n0 + a.n1; // half-stages per block (16-channel planes), even by construction (engine pads)
     // ring depths and LDS offsets: compile-time constants when the weights are streamed
     const int PR = WRES ? a.pr : C::PR, WR = WRES ? nst : C::WR;
-    const int kWOff = PR * kFPatch, kBiasOff = kWOff + WR * (EPI == 3 ? a.wpieces * 1024 : WB);
+    const int kWOff = PR * kFPatch, kBiasOff = kWOff + WR * (LAST3 ? a.wpieces * 1024 : WB);
 
     const int per = (a.nitems + 7) >> 3;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
@@ -274,7 +289,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         {
             // every weight image of the conv, once, ahead of the first patch: vector loads retire in order, so "P(0) has landed"
             // implies "all weights have landed"
-            const int npieces = nst * (EPI == 3 ? a.wpieces : C::WPIECES);
+            const int npieces = nst * (LAST3 ? a.wpieces : C::WPIECES);
             if (!RSR_ABL(1 | 64))
                 for (int p_ = lw; p_ < npieces; p_ += 4)
                     __builtin_amdgcn_global_load_lds(RSR_GLB(static_cast<const char*>(a.wpk16) + p_ * 1024 + lane * 16), RSR_LDS(smem + kWOff + p_ * 1024), 16, 0, 0);
@@ -356,8 +371,8 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // accumulator -> ds_write_b64 x4 -> ds_read_b128 x2 -> store per row; the 64 lanes of a store cover the same 1 KiB either
     // way, and the (pixel, half) lane order stores as fast as the pixel-pair order: tools/ubench/store_pattern.hip).
     const float slope = a.lrelu ? 0.2f : 1.f;
-    const bool idt = (EPI == 2) && a.res1_in_acc; // a fetched first residual arrives as res2 with s2 = 1 (launch_conv_flow)
-    const bool has2 = (EPI == 2) && a.res2_kind == 1;
+    const bool idt = RESID && a.res1_in_acc; // a fetched first residual arrives as res2 with s2 = 1 (launch_conv_flow)
+    const bool has2 = EPI == 5 || ((EPI == 2) && a.res2_kind == 1);
 #ifdef RSR_FLOW_TRACE // experiment builds only: an s_memtime in the loop forces every lgkmcnt wait to 0 (SMEM returns out of order)
     const bool tracing = a.trace && blockIdx.x == 0 && wave == 0;
 #else
@@ -418,7 +433,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // The second residual (the RRDB input, every third conv5) is fetched ahead of its use when the registers allow it (one
     // n-tile per wave) -- rows 0-1 one half-stage before the epilogue, rows 2-3 into the same registers once the
     // epilogue is through with rows 0-1: four dependent HBM round trips per block otherwise.
-    constexpr bool PRE2 = (EPI == 2) && NTW == 1;
+    constexpr bool PRE2 = (EPI == 2 || EPI == 4) && NTW == 1; // (EPI 5 fetches lo rows at the start of its epilogue anyway: nothing to gain, 16 VGPRs to lose)
     u32x4 r2q[PRE2 ? 2 : 1][NTW][2]; // rows 0-1, then rows 2-3
     // Out-of-image lanes / rows read zeros through the buffer range check, like row_store drops them.
     auto res2_row = [&](u32x4 (&dst)[2], const OutDesc& o, int rr, int n) {
@@ -433,8 +448,32 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.voff, int(unsigned(y) * unsigned(o.W * kFPx) + poff), 0);
         }
     };
+    // the same fetch from the planes `off` bytes behind those of `s` (EPI 4 / 5: the lo planes of a residual; off == 0: there are none,
+    // the null resource returns zeros)
+    auto lo_row = [&](const PlaneSrc& s, long long off, u32x4 (&dst)[2], const OutDesc& o, int rr, int n) {
+        const int y = o.y0 + rr;
+        char* ub = uniform_ptr(const_cast<char*>(plane_ptr(s, o.slot, ntw0 * 2)) + off);
+        const unsigned pstride = unsigned(s.plane_stride);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+        {
+            const unsigned poff = unsigned(n * 2 + p) * pstride;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, off ? int(o.lim + poff) : 0, 0x00020000);
+            dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.voff, int(unsigned(y) * unsigned(o.W * kFPx) + poff), 0);
+        }
+    };
     auto res2_prefetch = [&](const WorkItem& w, int row0) { // rows row0, row0 + 1
-        if (!PRE2 || !has2) return;
+        if (!PRE2) return;
+        if (EPI == 4)
+        { // no second residual: the prefetch registers carry rows 0-1 of the first residual's lo planes
+            if (row0 != 0) return;
+            const OutDesc o = make_out(w, true);
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) lo_row(a.res1, a.lo1_off, r2q[PRE2 ? rr : 0][0], o, rr, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
+        if (!has2) return;
         const OutDesc o = make_out(w, true);
 #pragma unroll
         for (int rr = 0; rr < 2; rr++)
@@ -499,6 +538,50 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             __builtin_amdgcn_sched_barrier(0); // one plane at a time: interleaved, the two planes' temporaries do not fit the 168-VGPR kernels
         }
     };
+    // EPI 4 / 5, one row of one n-tile: everything in fp32, one rounding (see the template comment).  l1 / r2h / r2l: this lane's 16
+    // bytes per plane of residual 1's lo planes, of residual 2 and of residual 2's lo planes (the latter two: EPI 5 only).
+    constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+    auto row_emit4 = [&](const f32x16& acc, const OutDesc& o, int rr, int n, const u32x4 (&l1)[2], const u32x4 (&r2h)[2], const u32x4 (&r2l)[2]) {
+        const int y = o.y0 + rr;
+        char* ub = uniform_ptr(o.base);
+        char* ul = uniform_ptr(o.base + a.out_lo_off);
+        const unsigned pstride = unsigned(a.out16.plane_stride);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+        {
+            float f[8];
+            const half8 l = __builtin_bit_cast(half8, l1[p]);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+            {
+                float v = acc[p * 8 + e] * a.s1;
+                asm volatile("" : "+v"(v)); // every variant rounds the product before anything is added (see row_emit)
+                f[e] = __builtin_fmaf((float)l[e], kLoInv, v);
+            }
+            if (EPI == 5)
+            {
+                const half8 r = __builtin_bit_cast(half8, r2h[p]), q = __builtin_bit_cast(half8, r2l[p]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) f[e] = __builtin_fmaf((float)q[e], kLoInv, __builtin_fmaf(f[e], a.s2, (float)r[e]));
+            }
+            half8 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+            {
+                vh[e] = (_Float16)f[e];
+                float d = f[e] - (float)vh[e]; // exact: vh is f rounded to 11 bits
+                asm volatile("" : "+v"(d));
+                vl[e] = (_Float16)(d * kLoScale);
+            }
+            const unsigned poff = unsigned(n * 2 + p) * pstride;
+            const int voff = o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + poff);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, o.live ? int(o.lim + poff) : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vh), rs, voff, 0, 0);
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(ul, 0, (o.live && a.out_lo_off) ? int(o.lim + poff) : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vl), rl, voff, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     // conv_last (EPI 0): channels 0..2 of n-tile 0 -> planar fp16 [3][H][W] (the reference's `output` blob, consumed by
     // postproc_tiles), or -- non-TTA RGB -- straight into the uint8 image: realsr_postproc.comp:62-83 on the value rounded to
     // fp16 exactly as the planar path stores it (v*255 + 0.5, floor, clamp), at the tile's place minus the halo crop.
@@ -509,7 +592,8 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         const int yb = it.y0 + wrow * 4 + ((fold && l32 >= 16) ? 16 : 0);
         if (a.out_u8)
         {
-            const int ox = it.pad0 + x, ow = it.pad2 & 0xffff, oh = it.pad2 >> 16;
+            const int ox = it.pad0 + x, ow = pad2_w(it.pad2), oh = pad2_h(it.pad2);
+            uint8_t* const oimg = a.out_u8s[pad2_img(it.pad2)]; // (a merged batch: the tile's own image)
 #pragma unroll
             for (int rr = 0; rr < 4; rr++)
             {
@@ -518,11 +602,12 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 const int rx = x - a.out_u8_crop, ry = y - a.out_u8_crop;
                 if (rx >= 0 && rx < ow && ry >= 0 && ry < oh)
                 {
-                    uint8_t* o = a.out_u8 + ((long long)(it.pad1 + y) * a.out_u8_w + ox) * 3;
+                    uint8_t* o = oimg + ((long long)(it.pad1 + y) * a.out_u8_w + ox) * 3;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {
-                        float v = (float)(_Float16)val[rr][ch];
+                        // the reference's `output` blob is fp16 (realsr.cpp:44-46); precise mode converts the fp32 value itself
+                        float v = OUT32 ? val[rr][ch] : (float)(_Float16)val[rr][ch];
                         v = floorf(v * 255.f + 0.5f);
                         v = fminf(fmaxf(v, 0.f), 255.f);
                         o[a.out_u8_bgr ? 2 - ch : ch] = (uint8_t)v;
@@ -545,7 +630,8 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 {
                     float v = val[rr][ch];
                     if (a.lrelu) v = fmaxf(v, v * 0.2f);
-                    o[ch * hw + pix] = (_Float16)v;
+                    if (OUT32) reinterpret_cast<float*>(o)[ch * hw + pix] = v; // (the slot stride is given in bytes)
+                    else o[ch * hw + pix] = (_Float16)v;
                 }
             }
         }
@@ -691,14 +777,16 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // output channels, B = the centre-tap pixels) -- the epilogue has no residual to fetch.  Runs after the half-stage's
     // first step (every accumulator row is initialised by then) and before its dx = 2 step hands the slot back.
 #define RSR_IDTAP(ACC)                                                                                               \
-    if (EPI == 2 && idt)                                                                                             \
+    if (RESID && idt)                                                                                                \
     {                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         _Pragma("unroll") for (int n_ = 0; n_ < NTW; n_++) if ((ck >> 1) == ntw0 + n_)                               \
         {                                                                                                            \
             half8 idf;                                                                                               \
+            int l32i = l32;                                                                                          \
+            if (PREC) asm volatile("" : "+v"(l32i)); /* recomputed per use: hoisted, the two fragments cost the precise kernels 8 VGPRs they need */ \
             _Pragma("unroll") for (int e = 0; e < 8; e++) idf[e] =                                                   \
-                ((ck & 1) * 16 + hi * 8 + e == row_cout(l32)) ? (_Float16)a.res1_coef : (_Float16)0.f;               \
+                ((ck & 1) * 16 + hi * 8 + e == row_cout(l32i)) ? (_Float16)a.res1_coef : (_Float16)0.f;              \
             const char* cb_ = xbase(sP, 1);                                                                          \
             _Pragma("unroll") for (int rr = 0; rr < 4; rr++)                                                         \
             {                                                                                                        \
@@ -805,7 +893,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         a.trace[0] = t_arr;
         a.trace[1] = __builtin_amdgcn_s_memtime();
     }
-    if constexpr (EPI == 3)
+    if constexpr (LAST3)
     {
         // ---- conv_last, 64 -> 3: (dy, cout) in the M dimension -------------------------------------------------------------
         // With 3 real output channels a 32 x 32 x 16 MFMA has room for the three dy taps at once: A = the aux image
@@ -955,10 +1043,49 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 load_bias();
                 __builtin_amdgcn_sched_barrier(0);
             };
-            if (EPI == 0)
+            if (LASTG)
             {
                 planar_store(accA, it);
                 refill();
+            }
+            else if constexpr (PREC && NTW == 1)
+            {
+                // Register budget: 168 VGPRs, all four accumulator rows live at the start.  EPI 4: rows 0-1 of residual 1's lo planes came
+                // in with the prefetch, rows 2-3 are fetched here and land while rows 0-1 are stored.  EPI 5 (every third RDB, trunk_conv):
+                // rows 0-1 of residual 2 and of both residuals' lo planes are fetched here, rows 2-3 into the same registers once rows
+                // 0-1 are through: two exposed round trips per block, in 24 of the 352 launches.
+                const OutDesc o = make_out(it, true);
+                u32x4 la[2][2], ra[2][2];
+                if (EPI == 4)
+                {
+                    lo_row(a.res1, a.lo1_off, la[0], o, 2, 0);
+                    lo_row(a.res1, a.lo1_off, la[1], o, 3, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    row_emit4(accA[0][0], o, 0, 0, r2q[0][0], la[0], la[0]);
+                    row_emit4(accA[1][0], o, 1, 0, r2q[PRE2 ? 1 : 0][0], la[0], la[0]);
+                    row_emit4(accA[2][0], o, 2, 0, la[0], la[0], la[0]);
+                    refill();
+                    row_emit4(accA[3][0], o, 3, 0, la[1], la[0], la[0]);
+                }
+                else
+                {
+                    u32x4 rh[2][2];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; h2++)
+                    {
+#pragma unroll
+                        for (int k = 0; k < 2; k++)
+                        {
+                            res2_row(rh[k], o, 2 * h2 + k, 0);
+                            lo_row(a.res1, a.lo1_off, la[k], o, 2 * h2 + k, 0);
+                            lo_row(a.res2, a.lo2_off, ra[k], o, 2 * h2 + k, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        row_emit4(accA[2 * h2][0], o, 2 * h2, 0, la[0], rh[0], ra[0]);
+                        if (h2) refill();
+                        row_emit4(accA[2 * h2 + 1][0], o, 2 * h2 + 1, 0, la[1], rh[1], ra[1]);
+                    }
+                }
             }
             else
             {
@@ -1134,15 +1261,17 @@ static void flow_launch(const ConvArgs& a_in, int ncu, bool resident, int reserv
 
 // every instantiation the engine can reach, for the per-device opt-in to > 64 KiB of dynamic LDS
 #define RSR_FLOW_VARIANTS(F)                                                                                         \
-    F(1, 1, false, 0, false) F(1, 1, false, 1, false) F(1, 1, false, 1, true) F(1, 1, false, 2, false)               \
+    F(1, 1, false, 0, false) F(1, 1, false, 1, false) F(1, 1, false, 1, true) F(1, 1, false, 2, false) F(1, 1, false, 7, false) \
     F(1, 1, true, 1, false)                                                                                          \
-    F(2, 1, false, 1, false) F(2, 1, false, 2, false) F(2, 1, true, 1, false)                                        \
+    F(2, 1, false, 1, false) F(2, 1, false, 2, false) F(2, 1, true, 1, false) F(2, 1, false, 4, false) F(2, 1, false, 5, false) \
     F(2, 2, false, 1, false) F(2, 2, false, 2, false) F(2, 2, true, 1, false)
 
 hipError_t flow_init_device()
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_flow<1, 1, false, 3, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_flow<1, 1, false, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
 #define RSR_F(NT, NTW, UPS, EPI, DEFER)                                                                              \
     if (e == hipSuccess) e = flow_attr<NT, NTW, UPS, EPI, DEFER>();
     RSR_FLOW_VARIANTS(RSR_F)
@@ -1163,6 +1292,8 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
         // residual's slot: fp16(s1*acc)*1 + r rounds exactly like fp16(s1*acc) + r
         if (a.res2_kind) return false;
         a.res2 = a.res1;
+        a.lo2_off = a.lo1_off;
+        a.lo1_off = 0;
         a.res2_kind = 1;
         a.s2 = 1.f;
     }
@@ -1174,6 +1305,9 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
         if (a.res1_kind == 0 && a.res2_kind == 0) epi = 1;
         else if (a.res1_kind == 1 && (a.res2_kind == 0 || a.res2_kind == 1)) epi = 2;
         else return false;
+        // the precise residual stream: every residual form, and a plain conv that starts the stream (conv_first: its lo planes are kept)
+        if (a.precise && (epi == 2 || (epi == 1 && a.out_lo_off && !a.lrelu && !ups))) epi = a.res2_kind ? 5 : 4;
+        if (epi >= 4 && !a.res1_kind) a.res1 = a.out16; // (conv_first: lo1_off == 0, the null resource is built on a valid base)
     }
     else if ((!a.out_planar3 && !a.out_u8) || a.out16.base || a.res1_kind || a.res2_kind) return false;
     const bool ntw2 = (flags & 1) != 0, defer = !(flags & 2), res = !(flags & 4);
@@ -1192,8 +1326,10 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
             int grid = ncu & ~7;
             const int per = (a.nitems + 7) / 8;
             if (per * 8 < grid) grid = per * 8;
-            hipLaunchKernelGGL((conv3x3_flow<1, 1, false, 3, false, true>), dim3(grid), dim3(512), pr * kFPatch + nst * 3072 + 128, st, a);
+            if (a.precise) hipLaunchKernelGGL((conv3x3_flow<1, 1, false, 6, false, true>), dim3(grid), dim3(512), pr * kFPatch + nst * 3072 + 128, st, a);
+            else hipLaunchKernelGGL((conv3x3_flow<1, 1, false, 3, false, true>), dim3(grid), dim3(512), pr * kFPatch + nst * 3072 + 128, st, a);
         }
+        else if (epi == 0 && !ups && a.precise) flow_launch<1, 1, false, 7, false>(a, ncu, res, reserve, st);
         else if (epi == 0 && !ups) flow_launch<1, 1, false, 0, false>(a, ncu, res, reserve, st);
         else if (epi == 1 && !ups && defer) flow_launch<1, 1, false, 1, true>(a, ncu, res, reserve, st);
         else if (epi == 1 && !ups) flow_launch<1, 1, false, 1, false>(a, ncu, res, reserve, st);
@@ -1203,18 +1339,20 @@ bool launch_conv_flow(const ConvArgs& a_in, int nt, int ncu, int flags, hipStrea
         return true;
     }
     if (nt != 2 || epi == 0) return false;
-    if (ntw2)
+    if (ntw2 && epi < 4) // (the precise residual forms exist in the 8 x 32 wave layout only: their epilogue needs its SGPRs)
     {
         if (epi == 1 && !ups) flow_launch<2, 2, false, 1, false>(a, ncu, res, reserve, st);
         else if (epi == 1) flow_launch<2, 2, true, 1, false>(a, ncu, res, reserve, st);
-        else if (!ups) flow_launch<2, 2, false, 2, false>(a, ncu, res, reserve, st);
+        else if (epi == 2 && !ups) flow_launch<2, 2, false, 2, false>(a, ncu, res, reserve, st);
         else return false;
     }
     else
     {
         if (epi == 1 && !ups) flow_launch<2, 1, false, 1, false>(a, ncu, res, reserve, st);
         else if (epi == 1) flow_launch<2, 1, true, 1, false>(a, ncu, res, reserve, st);
-        else if (!ups) flow_launch<2, 1, false, 2, false>(a, ncu, res, reserve, st);
+        else if (epi == 4 && !ups) flow_launch<2, 1, false, 4, false>(a, ncu, res, reserve, st);
+        else if (epi == 5 && !ups) flow_launch<2, 1, false, 5, false>(a, ncu, res, reserve, st);
+        else if (epi == 2 && !ups) flow_launch<2, 1, false, 2, false>(a, ncu, res, reserve, st);
         else return false;
     }
     return true;

@@ -334,7 +334,7 @@ static void make_items(Plan::Batch& b, bool fold, int place4 = -1, int trim4 = 0
                 const BaseTile& t = b.tiles[size_t(s)];
                 p0 = t.out_x - place4;
                 p1 = t.out_y - out_row0 - place4; // rows relative to the first output row the caller's device buffer holds
-                p2 = t.out_w | (t.out_h << 16);
+                p2 = item_pad2(t.out_w, t.out_h, t.img);
             }
             append_block_items(b.items[lvl], s, H, W, m, mtop[lvl], p0, p1, p2, fold);
         }
@@ -386,8 +386,9 @@ static hipError_t upload_batch(Plan::Batch& b, char*& d, bool xcd_order = true)
     return err;
 }
 
-// per-slot workspace bytes per LR pixel: IN 64, FEA 128, 3 x RDB 384, UP1 4*128, UP2 16*128, HR 16*128, OUT3 16*6
-static constexpr long long kBytesPerPx = 64 + 128 + 3 * 384 + 512 + 2048 + 2048 + 96;
+// per-slot workspace bytes per LR pixel: IN 64, FEA 128, 3 x RDB 384, UP1 4*128, UP2 16*128, HR 16*128, OUT3 16*6;
+// precise mode: + the lo planes of FEA and of the three RDB x tensors (4 x 128), OUT3 in fp32 (16*12)
+long long Engine::bytes_per_px() const { return 64 + 128 + 3 * 384 + 512 + 2048 + 2048 + 96 + (precise ? 4 * 128 + 96 : 0); }
 static constexpr size_t kMaxPlans = 8;
 
 // What the device can give this engine's workspace right now: 90 % of (free memory + the workspace it already holds) minus the
@@ -411,10 +412,11 @@ long long Engine::device_avail(int w, int h, int c)
     return std::max<long long>(0, ((long long)f + held) / 10 * 9 - lanes_need);
 }
 
-int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
+int Engine::get_plan(int w, int h, int c, int tile0, int tile1, int nimg, Plan*& out)
 {
+    const long long kBytesPerPx = bytes_per_px();
     for (auto it = plans.begin(); it != plans.end(); ++it)
-        if (it->w == w && it->h == h && it->c == c && it->T == tilesize && it->P == prepadding && it->tta == tta &&
+        if (it->w == w && it->h == h && it->c == c && it->T == tilesize && it->P == prepadding && it->tta == tta && it->nimg == nimg && it->precise == precise && it->ntw2 == ((flow_flags & 1) != 0) &&
             it->tile0 == tile0 && it->tile1 == tile1 && it->budget_mb == max_workspace_mb && it->trim == trim_tail && it->xcd_order == xcd_order && it->fold == fold_cols &&
             it->clamp == ws_clamp_bytes)
         {
@@ -429,6 +431,8 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
     long long cap = 0;
     int mtw = 0, mth = 0;
     if (tile0 < 0 || tile1 > xtiles * ytiles || tile0 >= tile1) return fail(RSR_E_ARG, "tile range outside the image");
+    if (nimg < 1 || nimg > kMaxMerge || (nimg > 1 && (tile0 != 0 || tile1 != xtiles * ytiles))) return fail(RSR_E_ARG, "merged batches take whole images");
+    for (int im = 0; im < nimg; im++)
     for (int ti = tile0; ti < tile1; ti++)
         {
             const int yi = ti / xtiles, xi = ti - yi * xtiles;
@@ -449,6 +453,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
             t.out_y = yi * T * scale;
             t.out_w = twn * scale;
             t.out_h = thn * scale;
+            t.img = im;
             all.push_back(t);
             cap = std::max(cap, (long long)t.tw * t.th);
             mtw = std::max(mtw, t.tw);
@@ -458,8 +463,15 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
     // largest plane is the 4x level, 16 * cap pixels * 32 B, and an MFMA wave reaches the 2 planes of its n-tile (4 with two n-tiles
     // per wave, flow_flags bit 0) from one base; the stores' range limit is "end of the plane + the plane's offset" (conv_flow.hip
     // make_out), which must stay below the sentinel too.  Tiles beyond that (~1,400 px) must be split by the caller.
-    if (cap * 16 * 32 * ((flow_flags & 1) ? 4 : 2) + 4 * kGuard >= (1ll << 31))
-        return fail(RSR_E_ARG, "tilesize too large: a padded tile may have at most 2,097,143 pixels (e.g. -t 1400)");
+    {
+        const long long reach = (flow_flags & 1) ? 4 : 2; // planes an MFMA wave addresses from one base
+        if (cap * 16 * 32 * reach + 4 * kGuard >= (1ll << 31))
+        {
+            const long long max_px = ((1ll << 31) - 4 * kGuard - 1) / (16 * 32 * reach);
+            return fail(RSR_E_ARG, "tilesize too large: a padded tile may have at most " + std::to_string(max_px) + " pixels" +
+                                       ((flow_flags & 1) ? " with flow_flags bit 0 (e.g. -t 1000)" : " (e.g. -t 1400)"));
+        }
+    }
     const int per = tta ? 8 : 1;
     const long long per_slot = cap * kBytesPerPx;
     // Memory policy (the reference bounds device memory through the tile size alone, main.cpp:761-774; here ALL tiles of an image
@@ -480,6 +492,9 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out)
 
     Plan plan;
     plan.w = w; plan.h = h; plan.c = c; plan.T = T; plan.P = P; plan.tta = tta;
+    plan.nimg = nimg;
+    plan.precise = precise;
+    plan.ntw2 = (flow_flags & 1) != 0;
     plan.tile0 = tile0; plan.tile1 = tile1;
     plan.budget_mb = max_workspace_mb;
     plan.trim = trim_tail;
@@ -563,15 +578,17 @@ int Engine::ensure_workspace(int nslots, long long cap, hipStream_t st)
     const size_t n = size_t(nslots), c = size_t(cap), G = size_t(kGuard), ppx = size_t(pc) * 2;
     const size_t p32 = size_t(32 / pc), p64 = size_t(64 / pc);
     const bool lc = cap != ws_cap_px; // the plane stride (hence the guard positions) depends on the slot capacity
-    const size_t need[] = {n * p32 * (c * ppx + G), n * p64 * (c * ppx + G), n * 3 * p64 * (c * ppx + G), n * p64 * (c * 4 * ppx + G),
-                           n * p64 * (c * 16 * ppx + G), n * c * 96};
+    // precise mode: FEA and the RDB buffers carry the lo planes of their 64-channel trunk tensor behind the hi / dense planes
+    const size_t fea_pps = precise ? 2 * p64 : p64, rdb_pps = precise ? 4 * p64 : 3 * p64;
+    const size_t need[] = {n * p32 * (c * ppx + G), n * fea_pps * (c * ppx + G), n * rdb_pps * (c * ppx + G), n * p64 * (c * 4 * ppx + G),
+                           n * p64 * (c * 16 * ppx + G), n * c * (precise ? 192 : 96)};
     DevBuf* const bufs[] = {&b_in, &b_fea, &b_rdb[0], &b_up1, &b_up2, &b_out3};
     bool any_grow = false;
     for (int i = 0; i < 6; i++)
         if (need[i] && !(bufs[i]->bytes >= need[i] && bufs[i]->p)) any_grow = true;
     if (ws_fail_above_bytes >= 0)
     { // test hook (option "ws_fail_above_mb"): a device on which workspaces above this size persistently fail to allocate
-        const long long total = (long long)nslots * cap * kBytesPerPx;
+        const long long total = (long long)nslots * cap * bytes_per_px();
         if (total > ws_fail_above_bytes)
         {
             ws_failures++;
@@ -680,12 +697,15 @@ int Engine::launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st)
     return RSR_OK;
 }
 
-int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out, int fused_out_w, int split_slot, hipEvent_t ev_half)
+int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs, int nimg, int fused_out_w, int split_slot, hipEvent_t ev_half)
 {
     const long long cap = ws_cap_px;
     const int pc = plane_ch(), P32 = 32 / pc, P64 = 64 / pc;
     const long long ppx = pc * 2;
     const long long pb16 = cap * ppx + kGuard; // planes are guarded (see ensure_workspace)
+    // precise mode (ConvArgs::precise): the lo planes of a trunk tensor sit behind the hi / dense planes of its slot
+    const int fea_pps = precise ? 2 * P64 : P64, rdb_pps = precise ? 4 * P64 : 3 * P64;
+    const long long fea_lo = precise ? P64 * pb16 : 0, rdb_lo = precise ? 3 * P64 * pb16 : 0;
     auto PS = [](const DevBuf& buf, long long planes_per_slot, long long plane_bytes, int plane_off) {
         PlaneSrc s; // base = pixel 0 of plane `plane_off` of slot 0
         s.base = static_cast<const char*>(buf.p) + (long long)plane_off * plane_bytes + kGuard;
@@ -715,6 +735,7 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         a.dbg = dbg;
         a.trace = (trace_conv == ci) ? static_cast<unsigned long long*>(trace_buf.p) : nullptr;
         a.s1 = a.s2 = 1.f;
+        a.precise = precise ? 1 : 0;
         // x4.param order: ... RDB 69 | trunk_conv kNumConvs-5 | upconv1 -4 | upconv2 -3 | HRconv -2 | conv_last kNumConvs-1
         constexpr int kLast = kNumConvs - 1, kUp1 = kNumConvs - 4;
         a.margin = tail_margin(b.trim4, ci >= kUp1 ? kLast - ci : 4 + (kUp1 - 1 - ci));
@@ -724,15 +745,16 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         if (rc == RSR_OK) rc = launch(a, ci, b, st);
         ci++;
     };
-    const PlaneSrc fea = PS(b_fea, P64, pb16, 0);
-    auto rdb_x = [&](int i) { return PS(b_rdb[i], 3 * P64, pb16, 0); };
-    auto rdb_d = [&](int i, int k) { return PS(b_rdb[i], 3 * P64, pb16, P64 + k * P32); };
+    const PlaneSrc fea = PS(b_fea, fea_pps, pb16, 0);
+    auto rdb_x = [&](int i) { return PS(b_rdb[i], rdb_pps, pb16, 0); };
+    auto rdb_d = [&](int i, int k) { return PS(b_rdb[i], rdb_pps, pb16, P64 + k * P32); };
 
     { // conv_first (x4.param:4): IN -> FEA
         ConvArgs a = base_args(0, 0);
         a.src0 = PS(b_in, P32, pb16, 0);
         a.n0 = P32;
         a.out16 = fea;
+        a.out_lo_off = fea_lo; // the stream starts here: fea keeps its rounding residue too
         go(a);
     }
     for (int j = 0; j < kNumRDB; j++)
@@ -754,19 +776,23 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         a.src1 = rdb_d(bi, 0); a.n1 = 4 * P32;
         a.s1 = 0.2f;
         a.res1 = xs; a.res1_kind = 1; a.res1_in_acc = 1; a.res1_coef = 5.f; // 1/0.2, exact in fp16
+        a.lo1_off = (j == 0) ? fea_lo : rdb_lo;
         if (bi == 2)
         {
             a.s2 = 0.2f;
             a.res2 = (j == 2) ? fea : rdb_x(0); a.res2_kind = 1;
+            a.lo2_off = (j == 2) ? fea_lo : rdb_lo;
         }
         a.out16 = rdb_x((j + 1) % 3);
+        a.out_lo_off = rdb_lo;
         go(a);
     }
     { // trunk_conv + global skip: fea + conv(trunk)   (x4.param:994-995)
         ConvArgs a = base_args(0, 0);
         a.src0 = rdb_x(kNumRDB % 3); a.n0 = P64;
         a.res1 = fea; a.res1_kind = 1; a.s1 = 1.f;
-        a.out16 = rdb_x(1);
+        a.lo1_off = fea_lo;
+        a.out16 = rdb_x(1); // (only upconv1 reads it: no lo planes)
         go(a);
     }
     const PlaneSrc up1 = PS(b_up1, P64, cap * 4 * ppx + kGuard, 0), up2 = PS(b_up2, P64, cap * 16 * ppx + kGuard, 0),
@@ -817,9 +843,10 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
         { // conv_last 64 -> 3   (x4.param:1001), planar fp16 output = the reference's `output` blob
             ConvArgs a = base_args(2, 2);
             a.src0 = hr; a.n0 = P64;
-            if (fused_out)
-            { // non-TTA RGB with conv3x3_flow: conv_last applies realsr_postproc.comp itself and writes the image
-                a.out_u8 = fused_out;
+            if (fused_outs)
+            { // non-TTA RGB with conv3x3_flow: conv_last applies realsr_postproc.comp itself and writes the image(s)
+                a.out_u8 = fused_outs[0];
+                for (int i = 0; i < nimg && i < kMaxMerge; i++) a.out_u8s[i] = fused_outs[i];
                 a.out_u8_w = fused_out_w;
                 a.out_u8_crop = prepadding * scale;
                 a.out_u8_bgr = bgr ? 1 : 0;
@@ -827,7 +854,7 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
             else
             {
                 a.out_planar3 = b_out3.p;
-                a.planar3_slot_stride = cap * 96;
+                a.planar3_slot_stride = cap * (precise ? 192 : 96);
             }
             sub(a, 2);
             go(a);
@@ -844,6 +871,13 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out
 int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int tile0, int tile1, hipEvent_t ev_half,
                           size_t* half_rows)
 {
+    return enqueue_images(&d_in, &d_out, 1, w, h, c, st, tile0, tile1, ev_half, half_rows);
+}
+
+int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg, int w, int h, int c, hipStream_t st, int tile0, int tile1,
+                           hipEvent_t ev_half, size_t* half_rows)
+{
+    const long long kBytesPerPx = bytes_per_px();
     if (half_rows) *half_rows = 0;
     Plan* planp = nullptr;
     const int xtiles = (w + tilesize - 1) / tilesize;
@@ -873,7 +907,7 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
     }
     for (;;)
     {
-        rc = get_plan(w, h, c, tile0, tile1, planp);
+        rc = get_plan(w, h, c, tile0, tile1, nimg, planp);
         if (rc != RSR_OK) return rc;
         rc = ensure_workspace(planp->slots_per_batch, planp->cap_px, st);
         if (rc != RSR_E_NOMEM) break;
@@ -910,7 +944,9 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
     for (const Plan::Batch& b : plan.batches)
     {
         PreArgs pa;
-        pa.img = static_cast<const uint8_t*>(d_in);
+        std::memset(&pa, 0, sizeof pa);
+        for (int i = 0; i < nimg; i++) pa.imgs[i] = static_cast<const uint8_t*>(d_in[i]);
+        pa.nimgs = nimg;
         pa.w = w; pa.h = h; pa.c = c;
         pa.tiles = b.d_tiles;
         pa.ntiles = b.ntiles;
@@ -926,7 +962,7 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
         const bool fused = !tta && c == 3 && !(dbg & 8192);
         // host calls: split the 4x tail at a tile-row boundary so that the first output rows can travel while the rest is computed
         int split_slot = 0;
-        if (fused && ev_half && half_rows && plan.batches.size() == 1 && !profiling && !(dbg & 16384))
+        if (fused && nimg == 1 && ev_half && half_rows && plan.batches.size() == 1 && !profiling && !(dbg & 16384))
         {
             const int xt = xtiles, yt = b.ntiles / xt;
             if (yt >= 2 && b.ntiles == xt * yt && plan.tile0 % xt == 0)
@@ -935,23 +971,27 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
                 *half_rows = size_t(b.tiles[size_t(split_slot)].out_y - b.tiles[0].out_y); // output rows finished at ev_half
             }
         }
-        rc = run_network(b, st, fused ? static_cast<uint8_t*>(d_out) : nullptr, w * scale, split_slot, ev_half);
+        uint8_t* outs[kMaxMerge];
+        for (int i = 0; i < nimg; i++) outs[i] = static_cast<uint8_t*>(d_out[i]);
+        rc = run_network(b, st, fused ? outs : nullptr, nimg, w * scale, split_slot, ev_half);
         if (rc != RSR_OK) return rc;
         if (progress) // one call per TILE, like the reference's line per tile (realsr.cpp:481), issued when the tile's batch is enqueued
             for (int i = 1; i <= b.ntiles; i++) progress(done + i, total, progress_user);
         done += b.ntiles;
         if (fused) continue;
         PostArgs po;
+        std::memset(&po, 0, sizeof po);
         po.planar3 = b_out3.p;
-        po.slot_stride = plan.cap_px * 96;
+        po.f32 = precise ? 1 : 0;
+        po.slot_stride = plan.cap_px * (precise ? 192 : 96);
         po.tiles = b.d_tiles;
         po.ntiles = b.ntiles;
         po.tta = tta;
         po.crop = prepadding * scale;
-        po.out = static_cast<uint8_t*>(d_out);
+        for (int i = 0; i < nimg; i++) { po.outs[i] = outs[i]; po.in_imgs[i] = static_cast<const uint8_t*>(d_in[i]); }
+        po.nimgs = nimg;
         po.out_w = w * scale; po.out_h = h * scale; po.c = c;
         po.out_row0 = plan.out_row0;
-        po.in_img = static_cast<const uint8_t*>(d_in);
         po.in_w = w; po.in_h = h;
         po.tilesize = tilesize;
         po.bgr = bgr ? 1 : 0;
@@ -1268,9 +1308,9 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
 }
 
 // one tile through the network only (layer-level parity hook)
-int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out)
+int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out, float* out32)
 {
-    if (!in || !out || w < 1 || h < 1) return fail(RSR_E_ARG, "bad arguments");
+    if (!in || (!out && !out32) || w < 1 || h < 1) return fail(RSR_E_ARG, "bad arguments");
     std::lock_guard<std::mutex> lk(mu);
     if (!loaded) return fail(RSR_E_STATE, "net_forward before load");
     HIP_TRY(hipSetDevice(device));
@@ -1304,7 +1344,23 @@ int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out)
         profiling = was;
         he = hipStreamSynchronize(stream);
         if (he == hipSuccess) he = hipGetLastError();
-        if (he == hipSuccess && rc == RSR_OK) he = hipMemcpy(out, b_out3.p, npx * 16 * 6, hipMemcpyDeviceToHost);
+        if (he == hipSuccess && rc == RSR_OK && !precise)
+        {
+            if (out) he = hipMemcpy(out, b_out3.p, npx * 16 * 6, hipMemcpyDeviceToHost);
+            if (out32) rc = fail(RSR_E_STATE, "the fp32 output blob exists in precise mode only (rsr_set_option precise 1)");
+        }
+        else if (he == hipSuccess && rc == RSR_OK)
+        { // precise mode: conv_last left fp32; the fp16 view of it is rounded here, on the host
+            std::vector<float> tmp32(out32 ? 0 : npx * 16 * 3);
+            float* dst = out32 ? out32 : tmp32.data();
+            he = hipMemcpy(dst, b_out3.p, npx * 16 * 12, hipMemcpyDeviceToHost);
+            if (he == hipSuccess && out)
+                for (size_t i = 0; i < npx * 16 * 3; i++)
+                {
+                    const _Float16 hv = (_Float16)dst[i];
+                    std::memcpy(&out[i], &hv, 2);
+                }
+        }
     }
     cleanup();
     if (he != hipSuccess) return fail(RSR_E_DEVICE, std::string("net_forward: ") + hipGetErrorString(he));
@@ -1313,11 +1369,13 @@ int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out)
 
 // one convolution with caller-supplied weights (layer-level parity hook, include/realsr_hip.h rsr_conv3x3)
 int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout,
-                      int lrelu, uint16_t* out, float s1, int own_res, const uint16_t* res, float s2)
+                      int lrelu, uint16_t* out, float s1, int own_res, const uint16_t* res, float s2, bool prec, const uint16_t* in_lo,
+                      const uint16_t* res_lo, uint16_t* out_lo)
 {
     if (!in || !weight || !bias || !out || cin < 1 || cout < 1 || cout > 64 || h < 1 || w < 1) return fail(RSR_E_ARG, "bad arguments");
     const bool residual = s1 != 0.f;
     if (residual && (ups || lrelu || (own_res && cin < cout) || (cout % 32))) return fail(RSR_E_ARG, "residual form: no upsampling / activation, cout 32 or 64");
+    if (prec && (!residual || cout != 64 || (in_lo && !own_res) || (res_lo && !res))) return fail(RSR_E_ARG, "precise form: a residual form with 64 output channels");
     std::lock_guard<std::mutex> lk(mu);
     HIP_TRY(hipSetDevice(device));
     Model m;
@@ -1338,15 +1396,23 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     const size_t ipx = size_t(h) * w, opx = size_t(H) * W;
     // planar [cin][h][w] -> guarded planes [np][h][w][pch]
     const size_t ipl = ipx * size_t(pch) + kGuard / 2; // halfs per guarded input plane
-    std::vector<uint16_t> hin(size_t(np) * ipl, 0), hout(size_t(npo) * opx * size_t(pch), 0);
+    // precise form: the lo planes of a tensor follow its hi planes in the same allocation (kernels.h ConvArgs::lo1_off)
+    std::vector<uint16_t> hin(size_t(np + (in_lo ? npo : 0)) * ipl, 0), hout(size_t(npo) * (out_lo ? 2 : 1) * opx * size_t(pch), 0);
     for (int ch = 0; ch < cin; ch++)
         for (size_t p = 0; p < ipx; p++) hin[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = in[size_t(ch) * ipx + p];
+    if (in_lo)
+        for (int ch = 0; ch < cout; ch++)
+            for (size_t p = 0; p < ipx; p++) hin[size_t(np + ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = in_lo[size_t(ch) * ipx + p];
     std::vector<uint16_t> hres;
     if (residual && res)
     { // planar [cout][h][w] -> guarded planes like the input
-        hres.assign(size_t(npo) * ipl, 0);
+        hres.assign(size_t(npo) * (res_lo ? 2 : 1) * ipl, 0);
         for (int ch = 0; ch < cout; ch++)
-            for (size_t p = 0; p < ipx; p++) hres[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = res[size_t(ch) * ipx + p];
+            for (size_t p = 0; p < ipx; p++)
+            {
+                hres[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = res[size_t(ch) * ipx + p];
+                if (res_lo) hres[size_t(npo + ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = res_lo[size_t(ch) * ipx + p];
+            }
     }
     DevBuf d_w, d_in, d_out, d_tab, d_res;
     std::vector<WorkItem> items;
@@ -1388,19 +1454,23 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         if (residual)
         { // the epilogue forms of RDB conv5 / trunk_conv (run_network)
             a.s1 = s1;
+            a.precise = prec ? 1 : 0;
+            const long long res_lo_off = res_lo ? (long long)npo * (long long)ipl * 2 : 0;
             if (own_res)
             {
                 a.res1 = a.src0;
                 a.res1_kind = 1;
                 a.res1_in_acc = 1;
                 a.res1_coef = 1.f / s1;
+                a.lo1_off = in_lo ? (long long)np * (long long)ipl * 2 : 0;
             }
             if (res)
             {
                 const PlaneSrc rp{static_cast<char*>(d_res.p) + kGuard, 0, (long long)ipx * pch * 2 + kGuard};
-                if (own_res) { a.res2 = rp; a.res2_kind = 1; a.s2 = s2; }
-                else { a.res1 = rp; a.res1_kind = 1; } // trunk_conv form: v = s1*(conv+b) + res  (s2 unused)
+                if (own_res) { a.res2 = rp; a.res2_kind = 1; a.s2 = s2; a.lo2_off = res_lo_off; }
+                else { a.res1 = rp; a.res1_kind = 1; a.lo1_off = res_lo_off; } // trunk_conv form: v = s1*(conv+b) + res  (s2 unused)
             }
+            if (out_lo) a.out_lo_off = (long long)npo * (long long)opx * pch * 2;
         }
         a.out16 = PlaneSrc{d_out.p, 0, (long long)opx * pch * 2};
         a.items = reinterpret_cast<const WorkItem*>(static_cast<const char*>(d_tab.p) + 256);
@@ -1424,7 +1494,11 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     if (he != hipSuccess) return fail(RSR_E_DEVICE, std::string("conv_test: ") + hipGetErrorString(he));
     if (rc != RSR_OK) return rc;
     for (int ch = 0; ch < cout; ch++)
-        for (size_t p = 0; p < opx; p++) out[size_t(ch) * opx + p] = hout[(size_t(ch / pch) * opx + p) * size_t(pch) + size_t(ch % pch)];
+        for (size_t p = 0; p < opx; p++)
+        {
+            out[size_t(ch) * opx + p] = hout[(size_t(ch / pch) * opx + p) * size_t(pch) + size_t(ch % pch)];
+            if (out_lo) out_lo[size_t(ch) * opx + p] = hout[(size_t(npo + ch / pch) * opx + p) * size_t(pch) + size_t(ch % pch)];
+        }
     return RSR_OK;
 }
 

@@ -41,6 +41,9 @@ struct DevBuf
 struct Plan
 {
     int w = 0, h = 0, c = 0, T = 0, P = 0, tta = 0;
+    int nimg = 1;         // images of this geometry merged into one tile batch (kernels.h kMaxMerge); their tiles follow each other image by image
+    bool precise = false; // Engine::precise when the plan was built (the slots are larger: part of the cache key)
+    bool ntw2 = false;    // flow_flags bit 0 when the plan was built (an MFMA wave then reaches 4 planes from one base: the tile-size bound halves)
     int tile0 = 0, tile1 = 0; // tiles [tile0, tile1) of the image's tile grid, row-major (multi-GPU tile sharding)
     long long budget_mb = 0;
     bool trim = true, xcd_order = true, fold = true;
@@ -109,6 +112,11 @@ struct Engine
     int scale = 4, tilesize = 200, prepadding = 10;
     bool loaded = false;
     bool bgr = false; // pixel order of the caller's images: BGR(A) like the reference's Windows/WIC path (realsr.cpp:188-206,497-515)
+    // Precise residual stream (option "precise"; kernels.h ConvArgs::precise): the 64-channel trunk is kept as hi + lo fp16 planes and
+    // conv_last's fp32 result goes to the uint8 conversion unrounded.  Default off = the storage of the reference's Vulkan path
+    // (fp16 everywhere, realsr.cpp:44-46); on = half the distance to its fp32 CPU path (realsr.cpp:525-838), the bar of the parity tests.
+    bool precise = false;
+    long long bytes_per_px() const; // workspace bytes per padded LR pixel of a slot
     int flow_flags = 0; // launch_conv_flow flags
     int num_cu = 256;
     int dbg = 0; // ConvArgs::dbg ablation bits (profiling only)
@@ -184,24 +192,30 @@ struct Engine
     // only the output rectangles of
     // those tiles are written
     int process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, int tile0 = 0, int tile1 = -1);
-    int net_forward(const uint16_t* in, int w, int h, uint16_t* out);
+    int net_forward(const uint16_t* in, int w, int h, uint16_t* out, float* out32 = nullptr); // out32: the fp32 result (precise mode only)
     // out = act(conv + b); with s1 != 0: v = s1*(conv + b) [+ in[0:cout] when own_res] [, v = s2*v + res when res]
+    // precise form (in_lo / res_lo / out_lo, any may be null): the hi + lo / 2048 residual stream of ConvArgs::precise
     int conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout, int lrelu,
-                  uint16_t* out, float s1 = 0.f, int own_res = 0, const uint16_t* res = nullptr, float s2 = 1.f);
+                  uint16_t* out, float s1 = 0.f, int own_res = 0, const uint16_t* res = nullptr, float s2 = 1.f, bool prec = false,
+                  const uint16_t* in_lo = nullptr, const uint16_t* res_lo = nullptr, uint16_t* out_lo = nullptr);
 
     // ---- internals (call with `mu` held unless noted) ----
     static constexpr int plane_ch() { return kPlaneCh; }
     int ensure(DevBuf& b, size_t bytes);
     int ensure_planes(DevBuf& b, size_t bytes, long long plane_bytes, bool layout_changed, bool zero_all, hipStream_t st);
-    int get_plan(int w, int h, int c, int tile0, int tile1, Plan*& out);
+    int get_plan(int w, int h, int c, int tile0, int tile1, int nimg, Plan*& out);
     long long device_avail(int w, int h, int c);
     void free_workspace(hipStream_t st);
     int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
-    int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* fused_out = nullptr, int fused_out_w = 0, int split_slot = 0,
+    // fused_outs: non-null = conv_last writes the uint8 images itself (one pointer per image of the batch)
+    int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs = nullptr, int nimg = 1, int fused_out_w = 0, int split_slot = 0,
                     hipEvent_t ev_half = nullptr);
     int launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st);
     int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int tile0 = 0, int tile1 = -1,
                       hipEvent_t ev_half = nullptr, size_t* half_rows = nullptr);
+    // nimg images of one geometry as ONE tile batch (nimg <= kMaxMerge; whole images only when nimg > 1)
+    int enqueue_images(const void* const* d_in, void* const* d_out, int nimg, int w, int h, int c, hipStream_t st, int tile0 = 0, int tile1 = -1,
+                       hipEvent_t ev_half = nullptr, size_t* half_rows = nullptr);
     void mark_begin(hipStream_t st);
     void mark(int cls, double flops, double bytes, hipStream_t st, int conv_index = -1);
     void collect_profile(hipStream_t st);

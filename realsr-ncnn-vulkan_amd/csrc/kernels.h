@@ -28,14 +28,24 @@ constexpr int kPlaneCh = 16;                    // channels per plane
 constexpr int kFoldBit = 1 << 30;
 constexpr int kFoldMaxW = 14; // strip = left halo + <= 14 pixels + right halo = 16 patch columns
 
+// MERGED batches: the tiles of up to kMaxMerge small images of one geometry, handed in by concurrent rsr_process calls, walk the
+// network as ONE batch (engine.cpp: Combiner) -- a 256 x 256 image is 200 blocks for 256 CUs and costs as much per launch as four of
+// them.  Every image keeps its own device buffers: the kernels that touch images get the pointers by value and the tile's image index.
+constexpr int kMaxMerge = 16;
+
 struct WorkItem // 32 bytes: one aligned 2 x 16-byte fetch gives a workgroup everything about its block
 {
     int slot, y0, x0; // tile slot and block origin at this table's resolution level (x0 | kFoldBit: a folded block)
     int H, W;         // dims of the slot's tile at this level (output dims of the conv)
-    // 4x-level items of a non-TTA batch: image coordinates of tile pixel (0,0) (= out_x - crop, out_y - crop; may be negative)
-    // and the size of the tile's un-padded output rectangle, out_w | out_h << 16  (conv_last writes the image itself)
+    // 4x-level items of a non-TTA batch (conv_last writes the image itself): image coordinates of tile pixel (0,0) (= out_x - crop,
+    // out_y - crop; may be negative) and pad2 = item_pad2(out_w, out_h, image): the size of the tile's un-padded output rectangle
+    // (13 bits each) and the index of the tile's image in a merged batch (6 bits)
     int pad0, pad1, pad2;
 };
+__host__ __device__ inline int item_pad2(int out_w, int out_h, int img) { return out_w | ((img & 7) << 13) | (out_h << 16) | int((unsigned)(img >> 3) << 29); }
+__host__ __device__ inline int pad2_w(int p) { return p & 0x1fff; }
+__host__ __device__ inline int pad2_h(int p) { return (p >> 16) & 0x1fff; }
+__host__ __device__ inline int pad2_img(int p) { return ((p >> 13) & 7) | int(((unsigned)p >> 29) << 3); }
 
 struct TileDim
 {
@@ -89,6 +99,18 @@ struct ConvArgs
     const void* zeros; // >= 16 zero bytes in device memory (LDS-DMA source for out-of-image pixels)
     unsigned long long* trace; // optional: block 0 / wave 0 writes per-stage s_memtime stamps (profiling aid), 2 x u64 per stage
     int dbg;           // ablation switches for profiling: 1 skip DMA, 2 skip MFMA, 4 skip epilogue stores, ...  (realsr_hip.h)
+    // PRECISE residual stream (engine option "precise"; EPI 4 / 5 of conv3x3_flow).  The reference's Vulkan path rounds the 64-channel
+    // trunk to fp16 after every RDB / RRDB (fp16 storage, realsr.cpp:44-46); the bar is its fp32 CPU path (realsr.cpp:525-838).  Here
+    // a trunk value v lives as TWO fp16 planes: hi = fp16(v) -- the plane every conv reads, unchanged -- and lo = fp16((v - hi) * 2048)
+    // (the rounding residue, scaled so that it never becomes subnormal).  The residual adds of the epilogue use hi + lo / 2048.
+    // The lo planes of a tensor sit in the same allocation as its hi planes, a fixed number of bytes further on (same slot / plane
+    // strides): only that distance travels.  0 = the tensor has no lo planes.
+    int precise;          // 1: residual forms run the precise epilogue (out16 single-rounded from the fp32 value)
+    long long lo1_off;    // lo planes of res1 = res1 + lo1_off bytes
+    long long lo2_off;    // lo planes of res2
+    long long out_lo_off; // lo planes of the output = out16 + out_lo_off (0: not kept)
+    // fused conv_last: the uint8 image of every image of a (merged) batch; out_u8 == out_u8s[0] doubles as the mode flag
+    uint8_t* out_u8s[kMaxMerge];
 };
 
 // conv_flow.hip: half-stage ring on 16-channel planes.  flags: 1 = two n-tiles per MFMA wave for 64-cout convs, 2 = no deferred epilogue,
@@ -107,11 +129,13 @@ struct BaseTile
     int slot0;        // first slot (TTA: 8 consecutive slots)
     int out_x, out_y; // top-left of this tile's output rectangle in the x4 image
     int out_w, out_h; // size of that rectangle (tile_w_nopad*4, tile_h_nopad*4)
+    int img;          // image of a merged batch this tile belongs to (index into PreArgs::imgs / PostArgs::outs; 0 otherwise)
 };
 
 struct PreArgs
 {
-    const uint8_t* img; // HWC u8
+    const uint8_t* imgs[kMaxMerge]; // HWC u8, one per image of the batch (all w x h x c); BaseTile::img selects
+    int nimgs;
     int w, h, c;
     const BaseTile* tiles;
     int ntiles;
@@ -126,16 +150,18 @@ void launch_preproc_tiles(const PreArgs& a, int max_tw, int max_th, hipStream_t 
 
 struct PostArgs
 {
-    const void* planar3; // fp16 [3][4th][4tw] per slot
+    const void* planar3; // fp16 (f32: fp32) [3][4th][4tw] per slot
+    int f32;             // 1: precise mode, conv_last left its fp32 result (ConvArgs::precise)
     long long slot_stride;
     const BaseTile* tiles;
     int ntiles;
     int tta;
     int crop;   // prepadding*scale
-    uint8_t* out; // HWC u8 (4w x 4h x c)
+    uint8_t* outs[kMaxMerge]; // HWC u8 (4w x 4h x c), one per image of the batch
+    int nimgs;
     int out_w, out_h, c;
-    int out_row0; // `out` points at output row out_row0 of the x4 image (a tile range's device buffer holds only its rows)
-    const uint8_t* in_img; // for alpha (c==4): source image (w x h x 4)
+    int out_row0; // the outs point at output row out_row0 of the x4 image (a tile range's device buffer holds only its rows)
+    const uint8_t* in_imgs[kMaxMerge]; // for alpha (c==4): the source images (w x h x 4)
     int in_w, in_h;
     int tilesize;
     int bgr;

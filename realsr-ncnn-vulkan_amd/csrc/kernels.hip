@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void preproc_tiles(const PreArgs a)
     if (gx >= t.tw || gy >= t.th) return;
     const int x = reflect101(gx + t.x_org, a.w);
     const int y = reflect101(gy + t.y_org, a.h);
-    const uint8_t* p = a.img + ((long long)y * a.w + x) * a.c;
+    const uint8_t* p = a.imgs[__builtin_amdgcn_readfirstlane(t.img)] + ((long long)y * a.w + x) * a.c;
     const float norm_val = 1 / 255.f;
     const int i0 = a.bgr ? 2 : 0, i2 = a.bgr ? 0 : 2;
     half8 v0;
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void preproc_tiles_lds(const PreArgs a)
     const BaseTile t = a.tiles[blockIdx.z];
     const int gx0 = blockIdx.x * 32, gy0 = blockIdx.y * 32;
     if (gx0 >= t.tw || gy0 >= t.th) return;
+    const uint8_t* const img = a.imgs[__builtin_amdgcn_readfirstlane(t.img)];
     const int nx = min(32, t.tw - gx0), ny = min(32, t.th - gy0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // source column span [lo, hi] of the block's columns (every wave computes it for itself)
@@ -118,12 +119,12 @@ __global__ __launch_bounds__(256) void preproc_tiles_lds(const PreArgs a)
         {
             const long long ad = a0 + 4 * lane;
             uint32_t v;
-            if (ad + 4 <= total) v = *reinterpret_cast<const uint32_t*>(a.img + ad);
+            if (ad + 4 <= total) v = *reinterpret_cast<const uint32_t*>(img + ad);
             else
             { // the last bytes of the image: never read past its end
                 v = 0;
                 for (int e = 0; e < 4; e++)
-                    if (ad + e < total) v |= (uint32_t)a.img[ad + e] << (8 * e);
+                    if (ad + e < total) v |= (uint32_t)img[ad + e] << (8 * e);
             }
             *reinterpret_cast<uint32_t*>(&raw[r][4 * lane]) = v;
         }
@@ -186,7 +187,9 @@ void launch_preproc_tiles(const PreArgs& a, int max_tw, int max_th, hipStream_t 
     // Measured (tools/prepost_perf.py, profiles/r04_prepost.txt): 0.042 ms LDS-staged vs 0.032 ms per-pixel on a 1080p frame, 0.145 vs
     // 0.150 ms with the 8 TTA scatters -- the byte loads of the plain kernel are served by the caches, its 32-byte stores are whole
     // sectors: staging buys nothing here.  Default = the plain kernel; variant 2 forces the staged one (tests, A/B).
-    if (a.variant != 2 || a.plane_ch != 16 || (reinterpret_cast<uintptr_t>(a.img) & 3))
+    bool aligned = true; // (the staged kernel reads the images in dwords)
+    for (int i = 0; i < a.nimgs; i++) aligned = aligned && !(reinterpret_cast<uintptr_t>(a.imgs[i]) & 3);
+    if (a.variant != 2 || a.plane_ch != 16 || !aligned)
     {
         const dim3 grid((max_tw + 31) / 32, (max_th + 7) / 8, a.ntiles), block(256);
         hipLaunchKernelGGL(preproc_tiles, grid, block, 0, st, a);
@@ -228,17 +231,19 @@ __device__ __forceinline__ int clampi(int v, int n) { return v < 0 ? 0 : (v > n 
 
 // realsr_postproc.comp:47-89 and realsr_postproc_tta.comp:54-110 for a batch of tiles.
 // One thread per output pixel of the tile's un-padded x4 rectangle.
+template <typename TP> // element type of the planar blob: _Float16 (the reference's `output` blob) or float (precise mode)
 __global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
 {
     const BaseTile t = a.tiles[blockIdx.z];
+    const int im = __builtin_amdgcn_readfirstlane(t.img);
     const int gx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int gy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (gx >= t.out_w || gy >= t.out_h) return;
     const int w = t.tw * 4, h = t.th * 4;
     const long long cstep = (long long)w * h;
     const int sx = gx + a.crop, sy = gy + a.crop;
-    uint8_t* o = a.out + ((long long)(t.out_y - a.out_row0 + gy) * a.out_w + t.out_x + gx) * a.c;
-    const _Float16* b0 = reinterpret_cast<const _Float16*>(static_cast<const char*>(a.planar3) + (long long)t.slot0 * a.slot_stride);
+    uint8_t* o = a.outs[im] + ((long long)(t.out_y - a.out_row0 + gy) * a.out_w + t.out_x + gx) * a.c;
+    const TP* b0 = reinterpret_cast<const TP*>(static_cast<const char*>(a.planar3) + (long long)t.slot0 * a.slot_stride);
     float v[3];
     if (!a.tta)
     {
@@ -247,11 +252,11 @@ __global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
     }
     else
     {
-        const long long ss = a.slot_stride / 2;
+        const long long ss = a.slot_stride / (long long)sizeof(TP);
 #pragma unroll
         for (int q = 0; q < 3; q++)
         {
-            const _Float16* b = b0 + q * cstep;
+            const TP* b = b0 + q * cstep;
             // realsr_postproc_tta.comp:76-85
             const float v0 = (float)b[(long long)sy * w + sx];
             const float v1 = (float)b[ss + (long long)sy * w + (w - 1 - sx)];
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
         for (int j = 0; j < 4; j++)
         {
             const int yy = ay0 + clampi(by - 1 + j, ah);
-            const uint8_t* rp = a.in_img + ((long long)yy * a.in_w + ax0) * 4 + 3;
+            const uint8_t* rp = a.in_imgs[im] + ((long long)yy * a.in_w + ax0) * 4 + 3;
             rows[j] = (float)rp[clampi(bx - 1, aw) * 4] * cx[0] + (float)rp[clampi(bx, aw) * 4] * cx[1] +
                       (float)rp[clampi(bx + 1, aw) * 4] * cx[2] + (float)rp[clampi(bx + 2, aw) * 4] * cx[3];
         }
@@ -299,19 +304,21 @@ __global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
 // channel) block is read along ITS rows into an LDS tile and picked up transposed (34-half pitch: conflict-free).  The merge keeps
 // the shader's summation order (v0 + v1 + ... + v7) * 0.125.  The uint8 pixels are collected in LDS and leave as aligned dwords
 // (a 32-pixel row segment of the HWC image = 96 or 128 contiguous bytes).
+template <typename TP>
 __global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
 {
-    __shared__ _Float16 T[32][34];
+    __shared__ TP T[32][sizeof(TP) == 2 ? 34 : 33]; // pitch: conflict-free column reads for 2- and 4-byte elements
     __shared__ __attribute__((aligned(16))) unsigned char ob[32][128];
     const BaseTile t = a.tiles[blockIdx.z];
+    const int im = __builtin_amdgcn_readfirstlane(t.img);
     const int gx0 = blockIdx.x * 32, gy0 = blockIdx.y * 32;
     if (gx0 >= t.out_w || gy0 >= t.out_h) return;
     const int nx = min(32, t.out_w - gx0), ny = min(32, t.out_h - gy0);
     const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
     const int w = t.tw * 4, h = t.th * 4;
     const long long cstep = (long long)w * h;
-    const _Float16* b0 = reinterpret_cast<const _Float16*>(static_cast<const char*>(a.planar3) + (long long)t.slot0 * a.slot_stride);
-    const long long ss = a.slot_stride / 2;
+    const TP* b0 = reinterpret_cast<const TP*>(static_cast<const char*>(a.planar3) + (long long)t.slot0 * a.slot_stride);
+    const long long ss = a.slot_stride / (long long)sizeof(TP);
     float acc[4][3];
     const int sx = gx0 + lx + a.crop;
 #pragma unroll
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
             float v = 0.f;
             if (ok)
             {
-                const _Float16* b = b0 + q * cstep;
+                const TP* b = b0 + q * cstep;
                 v = (float)b[(long long)sy * w + sx];
                 if (a.tta)
                 { // realsr_postproc_tta.comp:76-79
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
             for (int q = 0; q < 3; q++)
             {
                 __syncthreads(); // the previous tile has been consumed
-                const _Float16* b = b0 + k * ss + q * cstep;
+                const TP* b = b0 + k * ss + q * cstep;
 #pragma unroll
                 for (int m = 0; m < 4; m++)
                 {
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
             for (int j = 0; j < 4; j++)
             {
                 const int yy = ay0 + clampi(by - 1 + j, ah);
-                const uint8_t* rp = a.in_img + ((long long)yy * a.in_w + ax0) * 4 + 3;
+                const uint8_t* rp = a.in_imgs[im] + ((long long)yy * a.in_w + ax0) * 4 + 3;
                 rows[j] = (float)rp[clampi(bx - 1, aw) * 4] * cx[0] + (float)rp[clampi(bx, aw) * 4] * cx[1] +
                           (float)rp[clampi(bx + 1, aw) * 4] * cx[2] + (float)rp[clampi(bx + 2, aw) * 4] * cx[3];
             }
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
     for (int i = tid; i < ny * nd; i += 256)
     {
         const int r = i / nd, d = i - r * nd;
-        uint8_t* o = a.out + ((long long)(t.out_y - a.out_row0 + gy0 + r) * a.out_w + t.out_x + gx0) * a.c;
+        uint8_t* o = a.outs[im] + ((long long)(t.out_y - a.out_row0 + gy0 + r) * a.out_w + t.out_x + gx0) * a.c;
         reinterpret_cast<uint32_t*>(o)[d] = reinterpret_cast<const uint32_t*>(&ob[r][0])[d];
     }
 }
@@ -417,14 +424,18 @@ void launch_postproc_tiles(const PostArgs& a, int max_ow, int max_oh, hipStream_
     // Measured (profiles/r04_prepost.txt): the TTA gather 0.92 ms staged vs 2.42 ms per-pixel on the C5 frame (2.26 vs 0.86 TB/s: the
     // transposed variants), but 0.19 vs 0.12 ms for the plain single-variant conversion.  Default: staged under TTA, plain otherwise.
     const bool staged = a.variant == 2 || (a.variant == 0 && a.tta);
-    if (!staged || (reinterpret_cast<uintptr_t>(a.out) & 3))
+    bool aligned = true; // (the staged kernel stores the image in dwords)
+    for (int i = 0; i < a.nimgs; i++) aligned = aligned && !(reinterpret_cast<uintptr_t>(a.outs[i]) & 3);
+    if (!staged || !aligned)
     {
         const dim3 grid((max_ow + 63) / 64, (max_oh + 3) / 4, a.ntiles), block(256);
-        hipLaunchKernelGGL(postproc_tiles, grid, block, 0, st, a);
+        if (a.f32) hipLaunchKernelGGL(postproc_tiles<float>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(postproc_tiles<_Float16>, grid, block, 0, st, a);
         return;
     }
     const dim3 grid((max_ow + 31) / 32, (max_oh + 31) / 32, a.ntiles), block(256);
-    hipLaunchKernelGGL(postproc_tiles_lds, grid, block, 0, st, a);
+    if (a.f32) hipLaunchKernelGGL(postproc_tiles_lds<float>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(postproc_tiles_lds<_Float16>, grid, block, 0, st, a);
 }
 
 // ---- shader-shaped kernels: same arithmetic, the shaders' own buffer layouts -----------------

@@ -195,12 +195,13 @@ int rsr_conv3x3_res(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, con
                     float s1, int own_input_residual, const uint16_t* res, float s2, uint16_t* out);
 
 /* The same residual forms as the engine runs them in precise mode (option "precise"; 64 output channels): every tensor of the
- * residual stream is hi + lo / 2048 in two fp16 blobs (lo = fp16((v - hi) * 2048), the rounding residue of hi = fp16(v)); the adds
- * are done in fp32 and rounded once.  in_lo: lo of in[0:64] (own_input_residual only), res_lo: lo of res, out_lo: receives the lo of
- * the result; any of the three may be NULL (= zero / not wanted).  Layouts as rsr_conv3x3_res. */
-int rsr_conv3x3_res_precise(rsr_ctx* ctx, const uint16_t* in, const uint16_t* in_lo, int cin, int h, int w, const float* weight,
-                            const float* bias, float s1, int own_input_residual, const uint16_t* res, const uint16_t* res_lo, float s2,
-                            uint16_t* out, uint16_t* out_lo);
+ * residual stream is hi + lo / 2048 -- hi = fp16(v) as ever, lo = the rounding residue (v - hi) * 2048 as ONE byte (bf8 / e5m2: the
+ * upper byte of an IEEE fp16); the adds are done in fp32 and rounded once.  in_lo: lo of in[0:64] (own_input_residual only),
+ * res_lo: lo of res, out_lo: receives the lo of the result; any of the three may be NULL (= zero / not wanted).  Planar [64][h][w],
+ * hi blobs fp16, lo blobs bytes. */
+int rsr_conv3x3_res_precise(rsr_ctx* ctx, const uint16_t* in, const uint8_t* in_lo, int cin, int h, int w, const float* weight,
+                            const float* bias, float s1, int own_input_residual, const uint16_t* res, const uint8_t* res_lo, float s2,
+                            uint16_t* out, uint8_t* out_lo);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct rsr_profile
@@ -244,11 +245,11 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "tail_group"        slots (tiles; x8 under TTA) per launch group of the 2x / 4x convs (default 0 = the whole batch at once).  Small
  *                       groups keep the 4x intermediates in the Infinity Cache between upconv2 -> HRconv -> conv_last; measured
  *                       worth <= 1.5 % of those launches on MI355X and a loss at the 2x level, hence off
- *   "precise"           1: the 64-channel residual stream of the network is kept as TWO fp16 values per element (the fp16 the convs
- *                       read + its rounding residue) and conv_last's fp32 result is converted to uint8 without an fp16 blob in
+ *   "precise"           1: the 64-channel residual stream of the network is kept as THREE bytes per element (the fp16 the convs read +
+ *                       one byte of its rounding residue) and conv_last's fp32 result is converted to uint8 without an fp16 blob in
  *                       between: half the distance to the reference's fp32 CPU path (realsr.cpp:525-838) that fp16 storage -- the
- *                       reference's own GPU path, realsr.cpp:44-46, and this engine's default (0) -- has; costs ~8 % more workspace
- *                       and the extra traffic of the lo planes in 93 of the 351 convolutions
+ *                       reference's own GPU path, realsr.cpp:44-46, and this engine's default (0) -- has; costs ~6 % more workspace
+ *                       and the extra traffic of the residue planes in 71 of the 351 convolutions
  *   "bgr"               1: the caller's images are BGR(A) (the reference's Windows build: WIC decodes to BGR, realsr.cpp:188-206,
  *                       497-515, realsr_preproc.comp:17-21); the network always sees RGB.  Default 0 = RGB(A)
  *   "max_lanes"         rsr_process calls in flight per context (default 4); "chunk_mb": download chunk for pageable

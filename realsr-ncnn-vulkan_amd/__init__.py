@@ -284,16 +284,18 @@ class RealSR:
         return out
 
     def conv3x3_res_precise(self, x, weight, bias, s1, own_input_residual=False, x_lo=None, res=None, res_lo=None, s2=1.0, want_lo=True):
-        """rsr_conv3x3_res_precise: the residual forms on the hi + lo / 2048 stream; returns (hi, lo) float16 (lo None unless want_lo)."""
+        """rsr_conv3x3_res_precise: the residual forms on the hi + lo / 2048 stream (hi float16, lo uint8 = bf8 bytes);
+        returns (hi, lo), lo None unless want_lo."""
         x = np.ascontiguousarray(x, dtype=np.float16)
         weight = np.ascontiguousarray(weight, dtype=np.float32)
         bias = np.ascontiguousarray(bias, dtype=np.float32)
         cin, h, w = x.shape
         assert weight.shape[0] == 64
-        f16 = lambda t: None if t is None else np.ascontiguousarray(t, dtype=np.float16)  # noqa: E731
-        x_lo, res, res_lo = f16(x_lo), f16(res), f16(res_lo)
+        u8 = lambda t: None if t is None else np.ascontiguousarray(t, dtype=np.uint8)  # noqa: E731
+        x_lo, res_lo = u8(x_lo), u8(res_lo)
+        res = None if res is None else np.ascontiguousarray(res, dtype=np.float16)
         out = np.empty((64, h, w), dtype=np.float16)
-        out_lo = np.empty((64, h, w), dtype=np.float16) if want_lo else None
+        out_lo = np.empty((64, h, w), dtype=np.uint8) if want_lo else None
         self._ck(self._L.rsr_conv3x3_res_precise(self._h, _p(x), _p(x_lo), cin, h, w, _p(weight), _p(bias), float(s1),
                                                  int(bool(own_input_residual)), _p(res), _p(res_lo), float(s2), _p(out), _p(out_lo)))
         return out, out_lo

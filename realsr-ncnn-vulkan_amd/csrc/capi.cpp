@@ -311,8 +311,8 @@ int rsr_conv3x3_res(rsr_ctx* ctx, const uint16_t* in, int cin, int h, int w, con
     return ctx->e.conv_test(in, cin, h, w, 0, weight, bias, cout, 0, out, s1, own_input_residual, res, s2);
 }
 
-int rsr_conv3x3_res_precise(rsr_ctx* ctx, const uint16_t* in, const uint16_t* in_lo, int cin, int h, int w, const float* weight, const float* bias,
-                            float s1, int own_input_residual, const uint16_t* res, const uint16_t* res_lo, float s2, uint16_t* out, uint16_t* out_lo)
+int rsr_conv3x3_res_precise(rsr_ctx* ctx, const uint16_t* in, const uint8_t* in_lo, int cin, int h, int w, const float* weight, const float* bias,
+                            float s1, int own_input_residual, const uint16_t* res, const uint8_t* res_lo, float s2, uint16_t* out, uint8_t* out_lo)
 {
     if (!ctx) return RSR_E_ARG;
     if (s1 == 0.f) return Engine::fail(RSR_E_ARG, "s1 must be non-zero");
@@ -386,6 +386,9 @@ int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value)
     else if (k == "lane_out_mb") *value = lanes_bytes(true) / 1048576.0;
     else if (k == "lane_in_mb") *value = lanes_bytes(false) / 1048576.0;
     else if (k == "last_test_us") *value = e.last_test_us;
+    else if (k == "merged_batches") *value = double(e.merged_batches.load());
+    else if (k == "merged_images") *value = double(e.merged_images.load());
+    else if (k == "merged_widest") *value = double(e.merged_widest.load());
     else return e.fail(RSR_E_ARG, "unknown stat " + k);
     return RSR_OK;
 }
@@ -408,6 +411,16 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
     }
     else if (k == "bgr")
         ctx->e.bgr = value != 0;
+    else if (k == "merge")
+    {
+        if (value < 1 || value > kMaxMerge) return ctx->e.fail(RSR_E_ARG, "merge out of range (1 .. 16)");
+        ctx->e.merge_max = int(value);
+    }
+    else if (k == "merge_target_items")
+    {
+        if (value < 1 || value > (1 << 20)) return ctx->e.fail(RSR_E_ARG, "merge_target_items out of range");
+        ctx->e.merge_target_items = int(value);
+    }
     else if (k == "precise")
         ctx->e.precise = value != 0; // plans are keyed by it (larger slots); the workspace grows on the next call
     else if (k == "flow_flags")

@@ -51,6 +51,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 __attribute__((may_alias)) f32x4_lds;
@@ -111,6 +112,13 @@ __device__ __forceinline__ char* uniform_ptr(const void* p)
     return reinterpret_cast<char*>((unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
+// four bf8 (e5m2) bytes -> fp32 (the byte selector of v_cvt_f32_bf8 is an immediate)
+__device__ __forceinline__ void bf8x4_to_f32(unsigned w, float (&o)[4])
+{
+    o[0] = __builtin_amdgcn_cvt_f32_bf8(int(w), 0); o[1] = __builtin_amdgcn_cvt_f32_bf8(int(w), 1);
+    o[2] = __builtin_amdgcn_cvt_f32_bf8(int(w), 2); o[3] = __builtin_amdgcn_cvt_f32_bf8(int(w), 3);
+}
+
 #define RSR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define RSR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 #define RSR_MFMA 0x8
@@ -136,9 +144,9 @@ __device__ __forceinline__ char* uniform_ptr(const void* p)
 // EPI: 0 generic (conv_last: planar fp16 [3][H][W] output)      1 v = act(acc)  -> fp16 planes      3 conv_last with (dy, cout) in M
 //      2 v = s1*acc (the conv's own input rides in the accumulator as an identity tap) [, v = s2*v + r2] -> fp16 planes
 //      4 / 5 the PRECISE forms of 2 without / with the second residual (engine option "precise"; 64 output channels): the residual
-//        stream is kept as hi + lo / 2048 in two fp16 planes per 16 channels (kernels.h ConvArgs::precise) --
-//        v = s1*acc + lo1/2048 [, v = s2*v + r2 + lo2/2048] in fp32, then ONE rounding: hi = fp16(v) -> out16 (what the next convs
-//        read), lo = fp16((v - hi) * 2048) -> the output's lo planes.  The reference's GPU path rounds the trunk 92 times on its way
+//        stream is kept as hi + lo / 2048, hi an fp16 plane as ever and lo ONE BYTE per element (bf8 = e5m2: the upper byte of an
+//        fp16; kernels.h ConvArgs::precise) -- v = s1*acc + lo1/2048 [, v = s2*v + r2 + lo2/2048] in fp32, then ONE rounding:
+//        hi = fp16(v) -> out16 (what the next convs read), lo = bf8((v - hi) * 2048) -> the output's lo planes (16 B per pixel).  The reference's GPU path rounds the trunk 92 times on its way
 //        through the 23 RRDBs (fp16 storage, realsr.cpp:44-46); this halves the engine's distance to the fp32 CPU path
 //        (realsr.cpp:525-838; profiles/r06_storage_emulation.txt).  Absent lo planes are read through a null buffer resource
 //        (zeros, no memory access) and written into one: the epilogue is branch-free.
@@ -435,6 +443,10 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // epilogue is through with rows 0-1: four dependent HBM round trips per block otherwise.
     constexpr bool PRE2 = (EPI == 2 || EPI == 4) && NTW == 1; // (EPI 5 fetches lo rows at the start of its epilogue anyway: nothing to gain, 16 VGPRs to lose)
     u32x4 r2q[PRE2 ? 2 : 1][NTW][2]; // rows 0-1, then rows 2-3
+#ifndef RSR_PREC_PRE
+#define RSR_PREC_PRE 2 // EPI 4: lo rows of residual 1 fetched one half-stage ahead of the epilogue (the rest at its start; 4 costs a spilled dword and is no faster: profiles/r06_precise_cost.txt)
+#endif
+    u32x2 l1q[EPI == 4 ? 4 : 1][2];  // EPI 4: the four lo rows of residual 1
     // Out-of-image lanes / rows read zeros through the buffer range check, like row_store drops them.
     auto res2_row = [&](u32x4 (&dst)[2], const OutDesc& o, int rr, int n) {
         const int y = o.y0 + rr;
@@ -450,26 +462,29 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     };
     // the same fetch from the planes `off` bytes behind those of `s` (EPI 4 / 5: the lo planes of a residual; off == 0: there are none,
     // the null resource returns zeros)
-    auto lo_row = [&](const PlaneSrc& s, long long off, u32x4 (&dst)[2], const OutDesc& o, int rr, int n) {
+    // A lo plane has the geometry of its hi plane at HALF the bytes (16 channels x 1 B per pixel, plane stride / 2): every byte offset
+    // of the hi addressing -- lane, row, plane, the range limit, the out-of-range sentinel -- is simply halved.
+    auto lo_row = [&](const PlaneSrc& s, long long off, u32x2 (&dst)[2], const OutDesc& o, int rr, int n) {
         const int y = o.y0 + rr;
-        char* ub = uniform_ptr(const_cast<char*>(plane_ptr(s, o.slot, ntw0 * 2)) + off);
-        const unsigned pstride = unsigned(s.plane_stride);
+        const unsigned hstride = unsigned(s.plane_stride) >> 1;
+        char* ub = uniform_ptr(const_cast<char*>(plane_ptr(s, o.slot, 0)) + off + (long long)(ntw0 * 2) * hstride);
 #pragma unroll
         for (int p = 0; p < 2; p++)
         {
-            const unsigned poff = unsigned(n * 2 + p) * pstride;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, off ? int(o.lim + poff) : 0, 0x00020000);
-            dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.voff, int(unsigned(y) * unsigned(o.W * kFPx) + poff), 0);
+            const unsigned poff = unsigned(n * 2 + p) * hstride;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, off ? int((o.lim >> 1) + poff) : 0, 0x00020000);
+            dst[p] = __builtin_amdgcn_raw_buffer_load_b64(rs, int(unsigned(o.voff) >> 1), int(unsigned(y) * unsigned(o.W * (kFPx / 2)) + poff), 0);
         }
     };
     auto res2_prefetch = [&](const WorkItem& w, int row0) { // rows row0, row0 + 1
         if (!PRE2) return;
         if (EPI == 4)
-        { // no second residual: the prefetch registers carry rows 0-1 of the first residual's lo planes
+        { // no second residual: the prefetch brings ALL FOUR rows of the first residual's lo planes (16 VGPRs, what rows 0-1 of a second
+          // residual cost EPI 2)
             if (row0 != 0) return;
             const OutDesc o = make_out(w, true);
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) lo_row(a.res1, a.lo1_off, r2q[PRE2 ? rr : 0][0], o, rr, 0);
+            for (int rr = 0; rr < RSR_PREC_PRE; rr++) lo_row(a.res1, a.lo1_off, l1q[EPI == 4 ? rr : 0], o, rr, 0);
             __builtin_amdgcn_sched_barrier(0);
             return;
         }
@@ -541,44 +556,54 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // EPI 4 / 5, one row of one n-tile: everything in fp32, one rounding (see the template comment).  l1 / r2h / r2l: this lane's 16
     // bytes per plane of residual 1's lo planes, of residual 2 and of residual 2's lo planes (the latter two: EPI 5 only).
     constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
-    auto row_emit4 = [&](const f32x16& acc, const OutDesc& o, int rr, int n, const u32x4 (&l1)[2], const u32x4 (&r2h)[2], const u32x4 (&r2l)[2]) {
+    auto row_emit4 = [&](const f32x16& acc, const OutDesc& o, int rr, int n, const u32x2 (&l1)[2], const u32x4 (&r2h)[2], const u32x2 (&r2l)[2]) {
         const int y = o.y0 + rr;
         char* ub = uniform_ptr(o.base);
-        char* ul = uniform_ptr(o.base + a.out_lo_off);
-        const unsigned pstride = unsigned(a.out16.plane_stride);
+        const unsigned pstride = unsigned(a.out16.plane_stride), hstride = pstride >> 1;
+        char* ul = uniform_ptr(const_cast<char*>(plane_ptr(a.out16, o.slot, 0)) + a.out_lo_off + (long long)(ntw0 * 2) * hstride);
 #pragma unroll
         for (int p = 0; p < 2; p++)
         {
-            float f[8];
-            const half8 l = __builtin_bit_cast(half8, l1[p]);
+            // four values at a time (one dword of each lo plane): the 168-VGPR budget has no room for a whole decoded row
+            half8 vh;
+            u32x2 vl;
+            const half8 r = __builtin_bit_cast(half8, r2h[p]);
 #pragma unroll
-            for (int e = 0; e < 8; e++)
+            for (int k = 0; k < 2; k++)
             {
-                float v = acc[p * 8 + e] * a.s1;
-                asm volatile("" : "+v"(v)); // every variant rounds the product before anything is added (see row_emit)
-                f[e] = __builtin_fmaf((float)l[e], kLoInv, v);
-            }
-            if (EPI == 5)
-            {
-                const half8 r = __builtin_bit_cast(half8, r2h[p]), q = __builtin_bit_cast(half8, r2l[p]);
+                float f[4], lf[4];
+                bf8x4_to_f32(l1[p][k], lf);
 #pragma unroll
-                for (int e = 0; e < 8; e++) f[e] = __builtin_fmaf((float)q[e], kLoInv, __builtin_fmaf(f[e], a.s2, (float)r[e]));
-            }
-            half8 vh, vl;
+                for (int e = 0; e < 4; e++)
+                {
+                    float v = acc[p * 8 + k * 4 + e] * a.s1;
+                    asm volatile("" : "+v"(v)); // every variant rounds the product before anything is added (see row_emit)
+                    f[e] = __builtin_fmaf(lf[e], kLoInv, v);
+                }
+                if (EPI == 5)
+                {
+                    bf8x4_to_f32(r2l[p][k], lf);
 #pragma unroll
-            for (int e = 0; e < 8; e++)
-            {
-                vh[e] = (_Float16)f[e];
-                float d = f[e] - (float)vh[e]; // exact: vh is f rounded to 11 bits
-                asm volatile("" : "+v"(d));
-                vl[e] = (_Float16)(d * kLoScale);
+                    for (int e = 0; e < 4; e++) f[e] = __builtin_fmaf(lf[e], kLoInv, __builtin_fmaf(f[e], a.s2, (float)r[k * 4 + e]));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    vh[k * 4 + e] = (_Float16)f[e];
+                    float t = f[e] - (float)vh[k * 4 + e]; // exact: vh is f rounded to 11 bits
+                    asm volatile("" : "+v"(t));
+                    f[e] = t * kLoScale; // <= half an ulp of vh, x 2048: never beyond 32768
+                }
+                int wq = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], 0, false);
+                wq = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], wq, true);
+                vl[k] = unsigned(wq);
             }
-            const unsigned poff = unsigned(n * 2 + p) * pstride;
-            const int voff = o.voff + int(unsigned(y) * unsigned(o.W * kFPx) + poff);
+            const unsigned poff = unsigned(n * 2 + p) * pstride, loff = unsigned(n * 2 + p) * hstride;
+            const unsigned rowoff = unsigned(y) * unsigned(o.W * kFPx);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, o.live ? int(o.lim + poff) : 0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vh), rs, voff, 0, 0);
-            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(ul, 0, (o.live && a.out_lo_off) ? int(o.lim + poff) : 0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vl), rl, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vh), rs, o.voff + int(rowoff + poff), 0, 0);
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(ul, 0, (o.live && a.out_lo_off) ? int((o.lim >> 1) + loff) : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(vl, rl, int(unsigned(o.voff) >> 1) + int((rowoff >> 1) + loff), 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1024,6 +1049,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                     if (cp == 0) { RSR_HALF_PLAIN(accA, Wa, Wa, true) }
                     else { RSR_HALF_PLAIN(accA, Wa, Wa, false) }
                     ck = cp + 1;
+                    if (PRE2 && cp + 2 >= nst) res2_prefetch(it, 0); // (the precise kernels: one n-tile per wave without double-buffered weights)
                     RSR_HALF_PLAIN(accA, Wa, Wa, false)
                 }
             }
@@ -1050,26 +1076,28 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
             }
             else if constexpr (PREC && NTW == 1)
             {
-                // Register budget: 168 VGPRs, all four accumulator rows live at the start.  EPI 4: rows 0-1 of residual 1's lo planes came
-                // in with the prefetch, rows 2-3 are fetched here and land while rows 0-1 are stored.  EPI 5 (every third RDB, trunk_conv):
-                // rows 0-1 of residual 2 and of both residuals' lo planes are fetched here, rows 2-3 into the same registers once rows
-                // 0-1 are through: two exposed round trips per block, in 24 of the 352 launches.
+                // Register budget: 168 VGPRs, all four accumulator rows live at the start.  EPI 4: the lo rows of residual 1 came in with
+                // the prefetch, one half-stage ahead -- nothing is fetched here.  EPI 5 (every third RDB, trunk_conv): rows 0-1 of
+                // residual 2 and of both residuals' lo planes are fetched here, rows 2-3 into the same registers once rows 0-1 are
+                // through: two exposed round trips per block, in 24 of the 352 launches.
                 const OutDesc o = make_out(it, true);
-                u32x4 la[2][2], ra[2][2];
                 if (EPI == 4)
                 {
-                    lo_row(a.res1, a.lo1_off, la[0], o, 2, 0);
-                    lo_row(a.res1, a.lo1_off, la[1], o, 3, 0);
+                    const u32x4 (&nor)[2] = r2q[0][0]; // (not read)
+#pragma unroll
+                    for (int rr = RSR_PREC_PRE; rr < 4; rr++) lo_row(a.res1, a.lo1_off, l1q[EPI == 4 ? rr : 0], o, rr, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    row_emit4(accA[0][0], o, 0, 0, r2q[0][0], la[0], la[0]);
-                    row_emit4(accA[1][0], o, 1, 0, r2q[PRE2 ? 1 : 0][0], la[0], la[0]);
-                    row_emit4(accA[2][0], o, 2, 0, la[0], la[0], la[0]);
-                    refill();
-                    row_emit4(accA[3][0], o, 3, 0, la[1], la[0], la[0]);
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++)
+                    {
+                        if (rr == 3) refill();
+                        row_emit4(accA[rr][0], o, rr, 0, l1q[EPI == 4 ? rr : 0], nor, l1q[0]);
+                    }
                 }
                 else
                 {
                     u32x4 rh[2][2];
+                    u32x2 la[2][2], ra[2][2];
 #pragma unroll
                     for (int h2 = 0; h2 < 2; h2++)
                     {

@@ -94,6 +94,8 @@ Engine::~Engine()
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : sync_events) (void)hipEventDestroy(e);
+    if (merge_mid) (void)hipEventDestroy(merge_mid);
+    if (merge_done) (void)hipEventDestroy(merge_done);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -387,8 +389,8 @@ static hipError_t upload_batch(Plan::Batch& b, char*& d, bool xcd_order = true)
 }
 
 // per-slot workspace bytes per LR pixel: IN 64, FEA 128, 3 x RDB 384, UP1 4*128, UP2 16*128, HR 16*128, OUT3 16*6;
-// precise mode: + the lo planes of FEA and of the three RDB x tensors (4 x 128), OUT3 in fp32 (16*12)
-long long Engine::bytes_per_px() const { return 64 + 128 + 3 * 384 + 512 + 2048 + 2048 + 96 + (precise ? 4 * 128 + 96 : 0); }
+// precise mode: + the one-byte lo planes of FEA and of the three RDB x tensors (4 x 64), OUT3 in fp32 (16*12)
+long long Engine::bytes_per_px() const { return 64 + 128 + 3 * 384 + 512 + 2048 + 2048 + 96 + (precise ? 4 * 64 + 96 : 0); }
 static constexpr size_t kMaxPlans = 8;
 
 // What the device can give this engine's workspace right now: 90 % of (free memory + the workspace it already holds) minus the
@@ -536,7 +538,7 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, int nimg, Plan*&
     char* d = static_cast<char*>(plan.d_tables);
     for (Plan::Batch& b : plan.batches)
     {
-        const hipError_t e = upload_batch(b, d, xcd_order);
+        const hipError_t e = upload_batch(b, d, xcd_order && nimg == 1); // (a merged plan is launched in prefixes: plain reversal, whose prefixes are suffixes)
         if (e != hipSuccess)
         {
             (void)hipFree(plan.d_tables);
@@ -577,9 +579,12 @@ int Engine::ensure_workspace(int nslots, long long cap, hipStream_t st)
     constexpr int pc = plane_ch();
     const size_t n = size_t(nslots), c = size_t(cap), G = size_t(kGuard), ppx = size_t(pc) * 2;
     const size_t p32 = size_t(32 / pc), p64 = size_t(64 / pc);
-    const bool lc = cap != ws_cap_px; // the plane stride (hence the guard positions) depends on the slot capacity
+    // the plane stride (hence the guard positions) depends on the slot capacity; precise mode moves the planes of a slot (its one-byte
+    // lo planes sit at half strides and run across plane boundaries: where they lay, the other layout has guards)
+    const bool lc = cap != ws_cap_px || precise != ws_precise;
     // precise mode: FEA and the RDB buffers carry the lo planes of their 64-channel trunk tensor behind the hi / dense planes
-    const size_t fea_pps = precise ? 2 * p64 : p64, rdb_pps = precise ? 4 * p64 : 3 * p64;
+    // (one byte per element: the four lo planes of a tensor take the room of two hi planes)
+    const size_t fea_pps = p64 + (precise ? p64 / 2 : 0), rdb_pps = 3 * p64 + (precise ? p64 / 2 : 0);
     const size_t need[] = {n * p32 * (c * ppx + G), n * fea_pps * (c * ppx + G), n * rdb_pps * (c * ppx + G), n * p64 * (c * 4 * ppx + G),
                            n * p64 * (c * 16 * ppx + G), n * c * (precise ? 192 : 96)};
     DevBuf* const bufs[] = {&b_in, &b_fea, &b_rdb[0], &b_up1, &b_up2, &b_out3};
@@ -608,6 +613,7 @@ int Engine::ensure_workspace(int nslots, long long cap, hipStream_t st)
     if ((rc = ensure(b_out3, need[5])) != RSR_OK) return rc;
     HIP_TRY(hipGetLastError());
     ws_cap_px = cap;
+    ws_precise = precise;
     return RSR_OK;
 }
 
@@ -697,14 +703,16 @@ int Engine::launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st)
     return RSR_OK;
 }
 
-int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs, int nimg, int fused_out_w, int split_slot, hipEvent_t ev_half)
+int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs, int nimg, int fused_out_w, int split_slot, hipEvent_t ev_half,
+                        hipEvent_t ev_mid, int mid_rdb, int nslots_used)
 {
+    const int nslots = (nslots_used > 0 && nslots_used < b.nslots) ? nslots_used : b.nslots;
     const long long cap = ws_cap_px;
     const int pc = plane_ch(), P32 = 32 / pc, P64 = 64 / pc;
     const long long ppx = pc * 2;
     const long long pb16 = cap * ppx + kGuard; // planes are guarded (see ensure_workspace)
     // precise mode (ConvArgs::precise): the lo planes of a trunk tensor sit behind the hi / dense planes of its slot
-    const int fea_pps = precise ? 2 * P64 : P64, rdb_pps = precise ? 4 * P64 : 3 * P64;
+    const int fea_pps = P64 + (precise ? P64 / 2 : 0), rdb_pps = 3 * P64 + (precise ? P64 / 2 : 0);
     const long long fea_lo = precise ? P64 * pb16 : 0, rdb_lo = precise ? 3 * P64 * pb16 : 0;
     auto PS = [](const DevBuf& buf, long long planes_per_slot, long long plane_bytes, int plane_off) {
         PlaneSrc s; // base = pixel 0 of plane `plane_off` of slot 0
@@ -730,6 +738,12 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fu
         // on the least recently used data.
         a.items = (alternate_order && (ci & 1) && b.d_items_rev[lvl_out]) ? b.d_items_rev[lvl_out] : b.d_items[lvl_out];
         a.nitems = int(b.items[lvl_out].size());
+        if (nslots < b.nslots)
+        { // the first `nslots` slots only: a prefix of the forward table = a suffix of the (plainly) reversed one
+            const int n = a.nitems, cnt = b.item_start[lvl_out][size_t(nslots)];
+            if (a.items == b.d_items_rev[lvl_out]) a.items = b.d_items_rev[lvl_out] + (n - cnt);
+            a.nitems = cnt;
+        }
         a.dims = b.d_dims;
         a.zeros = zeros.p;
         a.dbg = dbg;
@@ -786,6 +800,7 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fu
         a.out16 = rdb_x((j + 1) % 3);
         a.out_lo_off = rdb_lo;
         go(a);
+        if (j == mid_rdb && ev_mid && rc == RSR_OK && hipEventRecord(ev_mid, st) != hipSuccess) rc = fail(RSR_E_DEVICE, "hipEventRecord failed");
     }
     { // trunk_conv + global skip: fea + conv(trunk)   (x4.param:994-995)
         ConvArgs a = base_args(0, 0);
@@ -806,16 +821,16 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fu
     // (tiles are independent).  Items are sorted by slot, so a group is a contiguous range of the item tables (mirrored in
     // the reversed tables).
     const int ci_tail = ci;
-    const int gsz = tail_group_slots > 0 ? tail_group_slots : b.nslots;
-    for (int s0 = 0; s0 < b.nslots && rc == RSR_OK;)
+    const int gsz = tail_group_slots > 0 ? tail_group_slots : nslots;
+    for (int s0 = 0; s0 < nslots && rc == RSR_OK;)
     {
-        int s1 = std::min(b.nslots, s0 + gsz);
+        int s1 = std::min(nslots, s0 + gsz);
         if (split_slot > s0 && split_slot < s1) s1 = split_slot;
         ci = ci_tail;
         auto sub = [&](ConvArgs& a, int lvl) {
             const int n = int(b.items[lvl].size());
             const int i0 = b.item_start[lvl][size_t(s0)], cnt = b.item_start[lvl][size_t(s1)] - i0;
-            const bool rev = a.items == b.d_items_rev[lvl];
+            const bool rev = a.items >= b.d_items_rev[lvl] && a.items < b.d_items_rev[lvl] + n; // (base_args may have moved it to a suffix already)
             a.items = rev ? b.d_items_rev[lvl] + (n - i0 - cnt) : b.d_items[lvl] + i0;
             a.nitems = cnt;
         };
@@ -875,8 +890,9 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
 }
 
 int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg, int w, int h, int c, hipStream_t st, int tile0, int tile1,
-                           hipEvent_t ev_half, size_t* half_rows)
+                           hipEvent_t ev_half, size_t* half_rows, hipEvent_t ev_mid, int plan_nimg)
 {
+    if (plan_nimg < nimg) plan_nimg = nimg;
     const long long kBytesPerPx = bytes_per_px();
     if (half_rows) *half_rows = 0;
     Plan* planp = nullptr;
@@ -907,8 +923,11 @@ int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg
     }
     for (;;)
     {
-        rc = get_plan(w, h, c, tile0, tile1, nimg, planp);
+        rc = get_plan(w, h, c, tile0, tile1, plan_nimg, planp);
         if (rc != RSR_OK) return rc;
+        // (a merged batch narrower than its plan needs the slots of its own images only)
+        // (a merged batch narrower than its plan still gets the plan's workspace: growing it image by image as wider batches form
+        // would re-allocate and clear gigabytes a dozen times)
         rc = ensure_workspace(planp->slots_per_batch, planp->cap_px, st);
         if (rc != RSR_E_NOMEM) break;
         // The batch does not fit (a shared or partly used GPU): halve it and plan again, down to one tile (x8 under TTA).
@@ -941,15 +960,19 @@ int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg
     mark_begin(st);
     int done = 0, total = 0;
     for (const Plan::Batch& b : plan.batches) total += b.ntiles;
+    const int tiles_wanted = (tile1 - tile0) * nimg; // the tiles of the first nimg images (all of the plan's unless the batch is narrower)
     for (const Plan::Batch& b : plan.batches)
     {
+        const int ntiles = std::min(b.ntiles, tiles_wanted - b.tile0); // of this batch
+        if (ntiles <= 0) break;
+        const int nslots_used = ntiles * (tta ? 8 : 1);
         PreArgs pa;
         std::memset(&pa, 0, sizeof pa);
         for (int i = 0; i < nimg; i++) pa.imgs[i] = static_cast<const uint8_t*>(d_in[i]);
         pa.nimgs = nimg;
         pa.w = w; pa.h = h; pa.c = c;
         pa.tiles = b.d_tiles;
-        pa.ntiles = b.ntiles;
+        pa.ntiles = ntiles;
         pa.tta = tta;
         pa.in_plane = static_cast<char*>(b_in.p) + kGuard;
         pa.slot_stride = (32 / pc) * (plan.cap_px * pc * 2 + kGuard);
@@ -973,10 +996,14 @@ int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg
         }
         uint8_t* outs[kMaxMerge];
         for (int i = 0; i < nimg; i++) outs[i] = static_cast<uint8_t*>(d_out[i]);
-        rc = run_network(b, st, fused ? outs : nullptr, nimg, w * scale, split_slot, ev_half);
+        // the throttle event of a merged batch (Engine::submit_merged): behind the RDB that leaves about half an image's worth of network
+        // ahead -- the time the next batch's launches take to enqueue
+        const bool last_batch = b.tile0 + b.ntiles >= tiles_wanted;
+        rc = run_network(b, st, fused ? outs : nullptr, nimg, w * scale, split_slot, ev_half, last_batch ? ev_mid : nullptr,
+                         kNumRDB - 1 - std::max(2, kNumRDB / (2 * std::max(1, nimg))), nslots_used);
         if (rc != RSR_OK) return rc;
-        if (progress) // one call per TILE, like the reference's line per tile (realsr.cpp:481), issued when the tile's batch is enqueued
-            for (int i = 1; i <= b.ntiles; i++) progress(done + i, total, progress_user);
+        if (progress && nimg == 1) // one call per TILE, like the reference's line per tile (realsr.cpp:481), issued when the tile's batch is enqueued
+            for (int i = 1; i <= b.ntiles; i++) progress(done + i, total, progress_user); // (a merged batch: every caller reports its own image)
         done += b.ntiles;
         if (fused) continue;
         PostArgs po;
@@ -985,7 +1012,7 @@ int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg
         po.f32 = precise ? 1 : 0;
         po.slot_stride = plan.cap_px * (precise ? 192 : 96);
         po.tiles = b.d_tiles;
-        po.ntiles = b.ntiles;
+        po.ntiles = ntiles;
         po.tta = tta;
         po.crop = prepadding * scale;
         for (int i = 0; i < nimg; i++) { po.outs[i] = outs[i]; po.in_imgs[i] = static_cast<const uint8_t*>(d_in[i]); }
@@ -1013,6 +1040,30 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
 {
     if (!d_in || !d_out || w < 1 || h < 1 || (c != 3 && c != 4)) return fail(RSR_E_ARG, "bad image arguments");
     hipEvent_t done = nullptr;
+    if (!user_stream && sync)
+    { // a small image: merged with whatever other calls hand in meanwhile (Engine::submit_merged)
+        int T = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!loaded) return fail(RSR_E_STATE, "process before load");
+            if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
+            T = tilesize;
+        }
+        if (merge_width(w, h, c) > 1)
+        {
+            MergeReq r;
+            r.d_in = d_in; r.d_out = d_out; r.w = w; r.h = h; r.c = c; r.T = T;
+            const int rc = submit_merged(r);
+            if (rc != RSR_OK) return rc;
+            const hipError_t e = hipEventSynchronize(r.ev_done);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                give_event(r.ev_done);
+            }
+            if (e != hipSuccess) return fail(RSR_E_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+            return RSR_OK;
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!loaded) return fail(RSR_E_STATE, "process before load");
@@ -1049,6 +1100,144 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
         give_event(done);
         if (e != hipSuccess) return fail(RSR_E_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
     }
+    return RSR_OK;
+}
+
+// ---- merging small images across calls (engine.h) ---------------------------------------------
+// How many images of this geometry one merged batch may take: 1 = the image is not small (more than a quarter of the work items a
+// batch aims at: a few launches' worth of blocks per CU by itself) or merging is off; else as many as keep the batch at
+// `merge_target_items` LR-level work items (16 x 32 blocks; x8 under TTA), at most merge_max.  ONE plan of that width serves every
+// narrower batch (enqueue_images: plan_nimg).
+int Engine::merge_width(int w, int h, int c) const
+{
+    (void)c;
+    if (merge_max <= 1 || profiling) return 1;
+    const int T = tilesize, P = prepadding;
+    if (T < 1) return 1;
+    long long items = 0;
+    for (int y0 = 0; y0 < h; y0 += T)
+        for (int x0 = 0; x0 < w; x0 += T)
+        {
+            const long long th = std::min(y0 + T, h) - y0 + 2 * P, tw = std::min(x0 + T, w) - x0 + 2 * P;
+            items += ((th + kBlkH - 1) / kBlkH) * ((tw + kBlkW - 1) / kBlkW);
+            if (items * 4 > merge_target_items) return 1;
+        }
+    items *= tta ? 8 : 1;
+    if (items * 4 > merge_target_items) return 1;
+    return int(std::max<long long>(1, std::min<long long>(std::min(merge_max, kMaxMerge), merge_target_items / std::max<long long>(items, 1))));
+}
+
+// Enqueue the images of g[0..n) (one geometry) as ONE tile batch; records every request's ev_done behind it.
+int Engine::run_group(MergeReq* const* g, int n)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    if (!loaded || scale != 4) return fail(RSR_E_STATE, "context parameters changed while the call was in flight");
+    for (int i = 0; i < n; i++)
+        if (g[i]->T != tilesize) return fail(RSR_E_STATE, "context parameters changed while the call was in flight");
+    HIP_TRY(hipSetDevice(device));
+    const void* ins[kMaxMerge];
+    void* outs[kMaxMerge];
+    for (int i = 0; i < n; i++)
+    {
+        ins[i] = g[i]->d_in;
+        outs[i] = g[i]->d_out;
+        if (g[i]->ev_in) HIP_TRY(hipStreamWaitEvent(stream, g[i]->ev_in, 0));
+    }
+    if (!merge_mid && hipEventCreateWithFlags(&merge_mid, hipEventDisableTiming) != hipSuccess) merge_mid = nullptr;
+    merge_mid_used = false;
+    int rc = enqueue_images(ins, outs, n, g[0]->w, g[0]->h, g[0]->c, stream, 0, -1, nullptr, nullptr, merge_mid, merge_width(g[0]->w, g[0]->h, g[0]->c));
+    if (rc == RSR_OK)
+        for (int i = 0; i < n && rc == RSR_OK; i++)
+        {
+            if (!g[i]->ev_done)
+            {
+                g[i]->ev_done = take_event();
+                g[i]->pool_event = true;
+                if (!g[i]->ev_done) rc = fail(RSR_E_DEVICE, "hipEventCreate failed");
+            }
+            if (rc == RSR_OK && hipEventRecord(g[i]->ev_done, stream) != hipSuccess) rc = fail(RSR_E_DEVICE, "hipEventRecord failed");
+        }
+    if (rc == RSR_OK)
+    {
+        merge_mid_used = merge_mid != nullptr;
+        if (!merge_done && hipEventCreateWithFlags(&merge_done, hipEventDisableTiming) != hipSuccess) merge_done = nullptr;
+        merge_last_n = (merge_done && hipEventRecord(merge_done, stream) == hipSuccess) ? n : 0;
+        merged_batches++;
+        merged_images += n;
+        if (n > merged_widest.load()) merged_widest = n;
+    }
+    else
+    {
+        const std::string why = last_error();
+        (void)hipStreamSynchronize(stream); // kernels of the batch that did get enqueued use the callers' buffers
+        for (int i = 0; i < n; i++)
+            if (g[i]->pool_event)
+            {
+                give_event(g[i]->ev_done);
+                g[i]->ev_done = nullptr;
+                g[i]->pool_event = false;
+            }
+        return fail(rc, why);
+    }
+    return RSR_OK;
+}
+
+int Engine::submit_merged(MergeReq& r)
+{
+    std::unique_lock<std::mutex> lk(cq_mu);
+    cq.push_back(&r);
+    if (cq_leader)
+    {
+        cq_cv.wait(lk, [&]() { return r.done || r.lead; });
+        if (r.done)
+        {
+            if (r.rc != RSR_OK) return fail(r.rc, r.err);
+            return RSR_OK;
+        }
+    }
+    // This caller leads: its own request is at the head of the queue (it found the queue without a leader -- i.e. empty -- or the
+    // previous leader woke the head).
+    cq_leader = true;
+    r.lead = false;
+    while (!r.done)
+    {
+        // Throttle: the next batch is formed when the previous one is HALF WAY through the network -- its ~350 launches (1 - 2 ms of
+        // host time) are then enqueued underneath the second half, the GPU never waits, and while this thread waits further calls queue
+        // up behind it: that is what fills a batch (1.5 batch times of arrivals; measured in profiles/r06_small_images.txt).
+        hipEvent_t wait_ev = merge_mid_used ? merge_mid : nullptr;
+        lk.unlock();
+        if (wait_ev) (void)hipEventSynchronize(wait_ev);
+        lk.lock();
+        MergeReq* g[kMaxMerge];
+        int n = 0;
+        const MergeReq* head = cq.front();
+        const int width = merge_width(head->w, head->h, head->c);
+        for (MergeReq* q : cq)
+            if (n < width && q->w == head->w && q->h == head->h && q->c == head->c && q->T == head->T) g[n++] = q;
+        // Every width up to merge_width shares one plan (enqueue_images: plan_nimg), so any number can be taken.  All of them when the GPU
+        // has run dry.  While the previous batch is still running, though, taking everything that waits makes the batch sizes
+        // ALTERNATE for ever (the callers of batch n - 1 are exactly what waits when batch n + 1 is formed: 1, 15, 1, 15 ... is as stable
+        // as 8, 8, 8, 8 and much slower): take half of (waiting + in flight), the rest leads the next batch.
+        int take = n;
+        if (merge_last_n > 0 && merge_done && hipEventQuery(merge_done) == hipErrorNotReady) take = std::min(n, std::max(1, (n + merge_last_n + 1) / 2));
+        (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+        for (int i = 0; i < take; i++) cq.erase(std::find(cq.begin(), cq.end(), g[i]));
+        lk.unlock();
+        const int rc = run_group(g, take);
+        const std::string why = rc == RSR_OK ? std::string() : std::string(last_error());
+        lk.lock();
+        for (int i = 0; i < take; i++)
+        {
+            g[i]->rc = rc;
+            g[i]->err = why;
+            g[i]->done = true;
+        }
+        cq_cv.notify_all();
+    }
+    if (!cq.empty()) cq.front()->lead = true; // hand over: the head of the queue forms the next batch
+    else cq_leader = false;
+    cq_cv.notify_all();
+    if (r.rc != RSR_OK) return fail(r.rc, r.err);
     return RSR_OK;
 }
 
@@ -1184,6 +1373,26 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
 
     // ---- network ----
     size_t half_rows = 0;
+    if (tile0 == 0 && tile1 == xtiles * ytiles && merge_width(w, h, c) > 1)
+    { // a small whole image: merged with the images other callers hand in meanwhile (Engine::submit_merged)
+        MergeReq r;
+        r.d_in = L->d_in.p; r.d_out = dbase; r.w = w; r.h = h; r.c = c; r.T = T;
+        r.ev_in = L->ev_in;
+        r.ev_done = L->ev_done;
+        rc = submit_merged(r);
+        if (rc != RSR_OK) return rc; // (a batch that failed half way has been drained by its leader: nothing of it is in flight)
+        guard.done_recorded = true;
+        void (*cb)(int, int, void*) = nullptr;
+        void* cb_user = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            cb = progress;
+            cb_user = progress_user;
+        }
+        if (cb)
+            for (int i = 1; i <= xtiles * ytiles; i++) cb(i, xtiles * ytiles, cb_user);
+    }
+    else
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!loaded || scale != 4 || tilesize != T)
@@ -1369,8 +1578,8 @@ int Engine::net_forward(const uint16_t* in, int w, int h, uint16_t* out, float* 
 
 // one convolution with caller-supplied weights (layer-level parity hook, include/realsr_hip.h rsr_conv3x3)
 int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout,
-                      int lrelu, uint16_t* out, float s1, int own_res, const uint16_t* res, float s2, bool prec, const uint16_t* in_lo,
-                      const uint16_t* res_lo, uint16_t* out_lo)
+                      int lrelu, uint16_t* out, float s1, int own_res, const uint16_t* res, float s2, bool prec, const uint8_t* in_lo,
+                      const uint8_t* res_lo, uint8_t* out_lo)
 {
     if (!in || !weight || !bias || !out || cin < 1 || cout < 1 || cout > 64 || h < 1 || w < 1) return fail(RSR_E_ARG, "bad arguments");
     const bool residual = s1 != 0.f;
@@ -1396,23 +1605,25 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     const size_t ipx = size_t(h) * w, opx = size_t(H) * W;
     // planar [cin][h][w] -> guarded planes [np][h][w][pch]
     const size_t ipl = ipx * size_t(pch) + kGuard / 2; // halfs per guarded input plane
-    // precise form: the lo planes of a tensor follow its hi planes in the same allocation (kernels.h ConvArgs::lo1_off)
+    // precise form: the one-byte lo planes of a tensor (plane stride / 2) follow its hi planes in the same allocation, `lo_off` bytes
+    // behind pixel 0 of plane 0 (kernels.h ConvArgs::lo1_off)
+    const size_t ipl_b = ipl * 2, opl_b = opx * size_t(pch) * 2; // bytes per (guarded) input plane / per output plane
     std::vector<uint16_t> hin(size_t(np + (in_lo ? npo : 0)) * ipl, 0), hout(size_t(npo) * (out_lo ? 2 : 1) * opx * size_t(pch), 0);
     for (int ch = 0; ch < cin; ch++)
         for (size_t p = 0; p < ipx; p++) hin[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = in[size_t(ch) * ipx + p];
-    if (in_lo)
+    auto put_lo = [&](std::vector<uint16_t>& buf, size_t lo_off, const uint8_t* lo) {
+        unsigned char* b = reinterpret_cast<unsigned char*>(buf.data()) + kGuard + lo_off;
         for (int ch = 0; ch < cout; ch++)
-            for (size_t p = 0; p < ipx; p++) hin[size_t(np + ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = in_lo[size_t(ch) * ipx + p];
+            for (size_t p = 0; p < ipx; p++) b[size_t(ch / pch) * (ipl_b / 2) + p * size_t(pch) + size_t(ch % pch)] = lo[size_t(ch) * ipx + p];
+    };
+    if (in_lo) put_lo(hin, size_t(np) * ipl_b, in_lo);
     std::vector<uint16_t> hres;
     if (residual && res)
     { // planar [cout][h][w] -> guarded planes like the input
         hres.assign(size_t(npo) * (res_lo ? 2 : 1) * ipl, 0);
         for (int ch = 0; ch < cout; ch++)
-            for (size_t p = 0; p < ipx; p++)
-            {
-                hres[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = res[size_t(ch) * ipx + p];
-                if (res_lo) hres[size_t(npo + ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = res_lo[size_t(ch) * ipx + p];
-            }
+            for (size_t p = 0; p < ipx; p++) hres[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = res[size_t(ch) * ipx + p];
+        if (res_lo) put_lo(hres, size_t(npo) * ipl_b, res_lo);
     }
     DevBuf d_w, d_in, d_out, d_tab, d_res;
     std::vector<WorkItem> items;
@@ -1497,7 +1708,9 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         for (size_t p = 0; p < opx; p++)
         {
             out[size_t(ch) * opx + p] = hout[(size_t(ch / pch) * opx + p) * size_t(pch) + size_t(ch % pch)];
-            if (out_lo) out_lo[size_t(ch) * opx + p] = hout[(size_t(npo + ch / pch) * opx + p) * size_t(pch) + size_t(ch % pch)];
+            if (out_lo)
+                out_lo[size_t(ch) * opx + p] =
+                    reinterpret_cast<const unsigned char*>(hout.data())[size_t(npo) * opl_b + size_t(ch / pch) * (opl_b / 2) + p * size_t(pch) + size_t(ch % pch)];
         }
     return RSR_OK;
 }

@@ -11,7 +11,15 @@
 //     a private copy stream and events -- nothing of a call's data path is shared with another call;
 //   * the network itself runs on ONE compute stream over ONE workspace; calls enqueue their kernels under `mu`
 //     (a few hundred microseconds of host time) and the GPU executes them in that order.  A lane's upload runs
-//     ahead of, and its download behind, the other lanes' kernels: H2D(k+1) | kernels(k) | D2H(k-1) overlap.
+//     ahead of, and its download behind, the other lanes' kernels: H2D(k+1) | kernels(k) | D2H(k-1) overlap;
+//   * SMALL images of concurrent calls are MERGED: a 256 x 256 image is 200 blocks for 256 CUs -- every one of the 352
+//     launches costs its fixed ~14 us whatever it carries -- so calls whose image is small and of the same geometry
+//     are combined into ONE tile batch (up to kMaxMerge images, Engine::submit_merged): the caller that finds no leader
+//     becomes one, waits until the previous merged batch is half way through the network (while it waits, further calls
+//     queue up; its own launches are then enqueued underneath the second half), takes the queued calls of its
+//     geometry and enqueues them as one batch; the others sleep until
+//     their batch is enqueued and then fetch their own output.  The reference runs such calls side by side on the
+//     device ("-j 4:4:4 for many small images", README.md:61, main.cpp:811-828); here they share the launches.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -91,6 +99,20 @@ struct CopyPool
     void copy(void* dst, const void* src, size_t n, int threads); // returns when all of [dst, dst+n) is written
 };
 
+// one image waiting to be merged into a tile batch (Engine::submit_merged); lives on its caller's stack
+struct MergeReq
+{
+    const void* d_in = nullptr;
+    void* d_out = nullptr;
+    int w = 0, h = 0, c = 0, T = 0;
+    hipEvent_t ev_in = nullptr;   // the input is complete behind this event (null: it already is)
+    hipEvent_t ev_done = nullptr; // recorded on the compute stream behind the batch (null: the leader takes one from the pool -> ev_done_pool)
+    bool pool_event = false;      // ev_done came from Engine::take_event: the caller gives it back
+    int rc = RSR_OK;
+    std::string err;
+    bool done = false, lead = false; // under Engine::cq_mu
+};
+
 // one in-flight rsr_process call (host API)
 struct Lane
 {
@@ -112,7 +134,7 @@ struct Engine
     int scale = 4, tilesize = 200, prepadding = 10;
     bool loaded = false;
     bool bgr = false; // pixel order of the caller's images: BGR(A) like the reference's Windows/WIC path (realsr.cpp:188-206,497-515)
-    // Precise residual stream (option "precise"; kernels.h ConvArgs::precise): the 64-channel trunk is kept as hi + lo fp16 planes and
+    // Precise residual stream (option "precise"; kernels.h ConvArgs::precise): the 64-channel trunk is kept as an fp16 plane + a byte of rounding residue and
     // conv_last's fp32 result goes to the uint8 conversion unrounded.  Default off = the storage of the reference's Vulkan path
     // (fp16 everywhere, realsr.cpp:44-46); on = half the distance to its fp32 CPU path (realsr.cpp:525-838), the bar of the parity tests.
     bool precise = false;
@@ -138,7 +160,7 @@ struct Engine
     long long ws_fail_above_bytes = -1; // test hook: workspaces above this size fail with RSR_E_NOMEM (a persistently fragmented device)
     long long ws_failures = 0;          // ... how often it fired (stat "ws_failures")
     int tail_group_slots = 0; // slots per launch group of the 2x / 4x convs (0 = the whole batch at once), see run_network
-    int max_lanes = 4;
+    int max_lanes = 16; // (small images are merged across calls: the more callers in flight, the fuller the launches)
     size_t chunk_bytes = size_t(16) << 20; // download chunk for pageable destinations
     int copy_threads = 4;                  // CPU threads per staging copy (1 = the calling thread alone)
     CopyPool pool;
@@ -151,6 +173,7 @@ struct Engine
 
     // workspace (one allocation per buffer kind), layout = slot capacity
     long long ws_cap_px = 0;
+    bool ws_precise = false; // Engine::precise the workspace was last laid out for
     DevBuf b_in, b_fea, b_rdb[3], b_up1, b_up2, b_hr, b_out3;
 
     // plans, most recently used first
@@ -160,6 +183,22 @@ struct Engine
     std::mutex lane_mu;
     std::condition_variable lane_cv;
     std::vector<std::unique_ptr<Lane>> lanes;
+
+    // merging small images across calls (see the top of this file)
+    int merge_max = kMaxMerge;       // option "merge": images per merged batch at most (1 = off)
+    int merge_target_items = 4096;   // LR-level work items a merged batch aims at (16 per CU); an image with more than a quarter of it is not merged
+    std::mutex cq_mu;
+    std::condition_variable cq_cv;
+    std::deque<MergeReq*> cq;        // FIFO of waiting calls, under cq_mu
+    bool cq_leader = false;          // some caller is forming / enqueuing a batch
+    hipEvent_t merge_mid = nullptr;  // recorded half way through the network of the last merged batch (the throttle of the next leader)
+    bool merge_mid_used = false;
+    hipEvent_t merge_done = nullptr; // ... and behind it
+    int merge_last_n = 0;            // images in that batch
+    std::atomic<long long> merged_batches{0}, merged_images{0}, merged_widest{0}; // stats
+    int merge_width(int w, int h, int c) const; // images of this geometry one batch may take (1: not a small image / merging off)
+    int submit_merged(MergeReq& r);             // returns when r's batch has been ENQUEUED (r.ev_done recorded) or failed
+    int run_group(MergeReq* const* g, int n);   // mu inside
 
     std::mutex mu; // compute section: plan cache, workspace, kernel enqueue, profiling state
     std::vector<hipEvent_t> sync_events; // free list, under mu
@@ -197,7 +236,7 @@ struct Engine
     // precise form (in_lo / res_lo / out_lo, any may be null): the hi + lo / 2048 residual stream of ConvArgs::precise
     int conv_test(const uint16_t* in, int cin, int h, int w, int ups, const float* weight, const float* bias, int cout, int lrelu,
                   uint16_t* out, float s1 = 0.f, int own_res = 0, const uint16_t* res = nullptr, float s2 = 1.f, bool prec = false,
-                  const uint16_t* in_lo = nullptr, const uint16_t* res_lo = nullptr, uint16_t* out_lo = nullptr);
+                  const uint8_t* in_lo = nullptr, const uint8_t* res_lo = nullptr, uint8_t* out_lo = nullptr);
 
     // ---- internals (call with `mu` held unless noted) ----
     static constexpr int plane_ch() { return kPlaneCh; }
@@ -208,14 +247,18 @@ struct Engine
     void free_workspace(hipStream_t st);
     int ensure_workspace(int nslots, long long cap_px, hipStream_t st);
     // fused_outs: non-null = conv_last writes the uint8 images itself (one pointer per image of the batch)
+    // ev_mid: recorded behind the middle RDB (a merged batch's throttle event)
+    // mid_rdb >= 0: ev_mid is recorded behind that RDB.  nslots_used < b.nslots: only the first slots of the batch (a merged batch narrower than its plan)
     int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs = nullptr, int nimg = 1, int fused_out_w = 0, int split_slot = 0,
-                    hipEvent_t ev_half = nullptr);
+                    hipEvent_t ev_half = nullptr, hipEvent_t ev_mid = nullptr, int mid_rdb = -1, int nslots_used = -1);
     int launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st);
     int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int tile0 = 0, int tile1 = -1,
                       hipEvent_t ev_half = nullptr, size_t* half_rows = nullptr);
     // nimg images of one geometry as ONE tile batch (nimg <= kMaxMerge; whole images only when nimg > 1)
+    // plan_nimg >= nimg: the plan is the one of plan_nimg images and only the first nimg of them are launched (every width of a merged
+    // batch shares ONE plan: slots, tiles and work items of an image are contiguous, so a narrower batch is a prefix of the tables)
     int enqueue_images(const void* const* d_in, void* const* d_out, int nimg, int w, int h, int c, hipStream_t st, int tile0 = 0, int tile1 = -1,
-                       hipEvent_t ev_half = nullptr, size_t* half_rows = nullptr);
+                       hipEvent_t ev_half = nullptr, size_t* half_rows = nullptr, hipEvent_t ev_mid = nullptr, int plan_nimg = 0);
     void mark_begin(hipStream_t st);
     void mark(int cls, double flops, double bytes, hipStream_t st, int conv_index = -1);
     void collect_profile(hipStream_t st);

@@ -101,10 +101,12 @@ struct ConvArgs
     int dbg;           // ablation switches for profiling: 1 skip DMA, 2 skip MFMA, 4 skip epilogue stores, ...  (realsr_hip.h)
     // PRECISE residual stream (engine option "precise"; EPI 4 / 5 of conv3x3_flow).  The reference's Vulkan path rounds the 64-channel
     // trunk to fp16 after every RDB / RRDB (fp16 storage, realsr.cpp:44-46); the bar is its fp32 CPU path (realsr.cpp:525-838).  Here
-    // a trunk value v lives as TWO fp16 planes: hi = fp16(v) -- the plane every conv reads, unchanged -- and lo = fp16((v - hi) * 2048)
-    // (the rounding residue, scaled so that it never becomes subnormal).  The residual adds of the epilogue use hi + lo / 2048.
-    // The lo planes of a tensor sit in the same allocation as its hi planes, a fixed number of bytes further on (same slot / plane
-    // strides): only that distance travels.  0 = the tensor has no lo planes.
+    // a trunk value v lives as hi = fp16(v) -- the plane every conv reads, unchanged -- and lo = bf8((v - hi) * 2048): the rounding
+    // residue as ONE byte (e5m2, i.e. the upper byte of an fp16; scaled so that it never becomes subnormal), 5 more bits of v than
+    // hi alone -- as good as an fp16 residue for this network (profiles/r06_storage_emulation.txt).  The residual adds of the
+    // epilogue use hi + lo / 2048.  The lo planes of a tensor ([H][W][16] bytes: the geometry of a hi plane at half the bytes, plane
+    // stride / 2) sit in the same allocation as its hi planes, a fixed number of bytes behind plane 0 (same slot stride): only that
+    // distance travels.  0 = the tensor has no lo planes.
     int precise;          // 1: residual forms run the precise epilogue (out16 single-rounded from the fp32 value)
     long long lo1_off;    // lo planes of res1 = res1 + lo1_off bytes
     long long lo2_off;    // lo planes of res2

@@ -1,0 +1,155 @@
+"""GPU tests of cross-call merging (engine.h: small images of concurrent rsr_process calls walk the network as ONE tile batch).
+
+The reference runs concurrent process() calls of its proc threads side by side on the device (main.cpp:811-828; README.md:61 "-j 4:4:4 for
+many small images"); here they share the launches.  A tile is computed the same way whoever shares its batch, so every image must come
+out BYTE-IDENTICAL to the one a lone call produces -- host and device API, RGB (conv_last writes the images itself), RGBA and TTA
+(planar blob + postproc), mixed geometries in flight at once, merging on and off."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import realsr_ncnn_vulkan_amd as R
+from realsr_ncnn_vulkan_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def paths(model_dir):
+    return os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin")
+
+
+def run_threads(n, fn):
+    errs = []
+
+    def wrap(i):
+        try:
+            fn(i)
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=wrap, args=(i,)) for i in range(n)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("c,tta,T", [(3, 0, 32), (4, 0, 32), (3, 1, 64)])
+def test_merged_images_equal_lone_calls(paths, oracle_net, c, tta, T):
+    """12 caller threads x 3 images each of TWO geometries on one context, host API: byte-identical to the serial outputs; batches of
+    more than one image did form; one image of the lot is also held against the oracle (+-1)."""
+    s = R.RealSR(0, tta_mode=bool(tta))
+    try:
+        s.load(*paths)
+        s.tilesize = T
+        geos = [(70, 52), (45, 33)]
+        imgs = [synth.make_image(100 + i, *geos[i % 2], c) for i in range(36)]
+        s.set_option("merge", 1)
+        lone = [s.process(im) for im in imgs]
+        assert s.get_stat("merged_batches") == 0
+        s.set_option("merge", 16)
+        assert s.get_stat("merged_batches") == 0
+        outs = [None] * 36
+
+        def work(t):
+            for k in range(3):
+                i = t * 3 + k
+                outs[i] = s.process(imgs[i], push_params=False)
+        run_threads(12, work)
+        for i in range(36):
+            assert np.array_equal(outs[i], lone[i]), i
+        nb, ni, widest = s.get_stat("merged_batches"), s.get_stat("merged_images"), s.get_stat("merged_widest")
+        print("c=%d tta=%d: %d images in %d merged batches, widest %d" % (c, tta, ni, nb, widest))
+        assert ni == 36 and nb < 36 and widest >= 2
+        ref = oracle_net.process(imgs[5], T, tta=bool(tta))
+        assert np.abs(outs[5].astype(int) - ref.astype(int)).max() <= 1
+    finally:
+        s.close()
+
+
+def test_merged_device_api_and_precise_mode(paths):
+    """The device API (synchronous rsr_process_device calls from 8 threads) merges too; precise mode (lo planes in the slots) likewise."""
+    import torch
+    s = R.RealSR(0)
+    try:
+        s.load(*paths)
+        s.tilesize = 64
+        for precise in (0, 1):
+            s.set_option("precise", precise)
+            imgs = [synth.make_image(300 + i, 90, 70) for i in range(16)]
+            d_in = [torch.from_numpy(im).cuda() for im in imgs]
+            d_out = [torch.zeros((280, 360, 3), dtype=torch.uint8, device="cuda") for _ in imgs]
+            s.set_option("merge", 1)
+            lone = [s.process(im) for im in imgs]
+            s.set_option("merge", 16)
+            b0 = s.get_stat("merged_batches")
+
+            def work(t):
+                for i in (2 * t, 2 * t + 1):
+                    s.process_device(d_in[i].data_ptr(), 90, 70, 3, d_out[i].data_ptr())
+            run_threads(8, work)
+            torch.cuda.synchronize()
+            for i in range(16):
+                assert np.array_equal(d_out[i].cpu().numpy(), lone[i]), (precise, i)
+            assert s.get_stat("merged_batches") - b0 < 16
+    finally:
+        s.close()
+
+
+def test_large_images_and_tile_ranges_are_not_merged(paths):
+    """An image that fills the chip by itself (more than a quarter of the work items a merged batch aims at) and calls over tile ranges
+    keep the single-call path (split tail, early download): no merged batch is counted, bytes as ever."""
+    s = R.RealSR(0)
+    try:
+        s.load(*paths)
+        s.tilesize = 200
+        img = synth.make_image(9, 1000, 700)  # 20 tiles of 220 x 220 = 1,960 work items
+        a = s.process(img)
+        assert s.get_stat("merged_batches") == 0
+        s.tilesize = 32
+        small = synth.make_image(10, 64, 64)
+        out = np.zeros((256, 256, 3), np.uint8)
+        s.process_rows(small, out, 0, 1)
+        assert s.get_stat("merged_batches") == 0
+        b = s.process(small)
+        assert s.get_stat("merged_batches") == 1 and np.array_equal(out[:128], b[:128])
+        s.set_option("merge_target_items", 8)  # nothing is small any more
+        assert np.array_equal(s.process(small), b) and s.get_stat("merged_batches") == 1
+        s.tilesize = 200
+        assert np.array_equal(s.process(img), a)
+    finally:
+        s.close()
+
+
+def test_a_failing_merged_batch_reports_to_every_caller(paths):
+    """A batch whose workspace cannot be had (test hook ws_fail_above_mb) fails EVERY call that was merged into it with RSR_E_NOMEM -- nobody
+    hangs, nobody gets a stale image -- and the context works again once the cause is gone."""
+    s = R.RealSR(0)
+    try:
+        s.load(*paths)
+        s.tilesize = 32
+        imgs = [synth.make_image(400 + i, 60, 60) for i in range(8)]
+        good = [s.process(im) for im in imgs]
+        s.set_option("ws_fail_above_mb", 0)
+        codes = [None] * 8
+
+        def work(i):
+            try:
+                s.process(imgs[i], push_params=False)
+                codes[i] = 0
+            except R.RealSRError as e:
+                codes[i] = e.code
+        run_threads(8, work)
+        assert codes == [R.RSR_E_NOMEM] * 8, codes
+        s.set_option("ws_fail_above_mb", -1)
+        s.set_option("ws_clamp_mb", -1)
+        outs = [None] * 8
+
+        def work2(i):
+            outs[i] = s.process(imgs[i], push_params=False)
+        run_threads(8, work2)
+        for i in range(8):
+            assert np.array_equal(outs[i], good[i]), i
+    finally:
+        s.close()

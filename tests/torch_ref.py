@@ -95,9 +95,10 @@ def rrdbnet_forward_storage(weights, x, trunk="fp16", out32=False, fea16=True):
     operands are fp16 whatever the storage is (MFMA operands), so x1..x4 and the tensors behind the up-samplings cannot gain anything;
     what can is
       trunk -- the 64-channel residual stream (every RDB / RRDB output, fea + trunk_conv): "fp16" = rounded at every stage (the
-               reference's GPU path, the engine's default), "fp32" = kept in fp32 for the residual ADDS, "split" = kept as two fp16
-               values hi = fp16(v), lo = fp16((v - hi) * 2048) (what the engine's precise mode stores: hi is the plane the convs read),
-               "rrdb" = fp32 only at the 23 RRDB outputs (diagnostic);
+               reference's GPU path, the engine's default), "fp32" = kept in fp32 for the residual ADDS, "split" = kept as
+               hi = fp16(v) + one byte lo = e5m2((v - hi) * 2048) (what the engine's precise mode stores: hi is the plane the convs
+               read), "split16" = the same with an fp16 residue (no better: profiles/r06_storage_emulation.txt), "rrdb" = fp32 only at the
+               23 RRDB outputs (diagnostic);
       fea16 -- conv_first's output rounded once (it is a conv operand AND the start of the stream; the engine keeps no lo for it);
       out32 -- conv_last's result goes to the uint8 conversion without an fp16 rounding in between.
     trunk="fp16", out32=False = rrdbnet_forward_fp16_storage."""
@@ -113,9 +114,13 @@ def rrdbnet_forward_storage(weights, x, trunk="fp16", out32=False, fea16=True):
 
     def split(t):
         hi = h(t)
+        return hi + ((t - hi) * 2048.0).to(torch.float8_e5m2).float() / 2048.0
+
+    def split16(t):
+        hi = h(t)
         return hi + h((t - hi) * 2048.0) / 2048.0
 
-    ht = {"fp16": h, "fp32": (lambda t: t), "split": split, "rrdb": h}[trunk]
+    ht = {"fp16": h, "fp32": (lambda t: t), "split": split, "split16": split16, "rrdb": h}[trunk]
     hr = (lambda t: t) if trunk == "rrdb" else ht
     fea = conv(x, False)
     fea = h(fea) if fea16 else ht(fea)

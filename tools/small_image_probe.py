@@ -54,23 +54,35 @@ def bench(ctxs, threads_per_ctx, w, h, frames, host=False):
 
 a = mk()
 print("256x256 tile 128, device-resident images, %d frames" % FR)
-for nthr in (1, 2, 4):
-    ms, mp = bench([a], nthr, 256, 256, FR)
-    print("  1 context x %d caller threads: %.2f ms per image, %.1f Mpix/s" % (nthr, ms, mp), flush=True)
-more = [mk() for _ in range(3)]
+for merge in (1, 16):
+    a.set_option("merge", merge)
+    for nthr in (1, 2, 4, 8, 16, 32):
+        b0, i0 = a.get_stat("merged_batches"), a.get_stat("merged_images")
+        ms, mp = bench([a], nthr, 256, 256, max(FR, 4 * nthr))
+        nb, ni = a.get_stat("merged_batches") - b0, a.get_stat("merged_images") - i0
+        print("  merge=%2d, 1 context x %2d caller threads: %.2f ms per image, %.1f Mpix/s   (%.1f images per merged batch)" % (
+            merge, nthr, ms, mp, ni / nb if nb else 1.0), flush=True)
+a.set_option("merge", 1)
+more = [mk(merge=1) for _ in range(3)]
 for nc in (2, 4):
     ms, mp = bench([a] + more[:nc - 1], 1, 256, 256, FR)
-    print("  %d contexts x 1 thread: %.2f ms per image, %.1f Mpix/s" % (nc, ms, mp), flush=True)
-ms, mp = bench([a] + more, 2, 256, 256, FR)
-print("  4 contexts x 2 threads: %.2f ms per image, %.1f Mpix/s" % (ms, mp), flush=True)
+    print("  merge= 1, %d contexts x 1 thread: %.2f ms per image, %.1f Mpix/s" % (nc, ms, mp), flush=True)
 for c in more:
     c.close()
-print("merged batches (one image of the same tile count as k 256x256 images), 1 context x 1 thread:")
-for k, (w, h) in ((2, (512, 256)), (4, (512, 512)), (8, (1024, 512)), (16, (1024, 1024)), (32, (2048, 1024))):
+print("one image of the same tile count as k 256x256 images (what a merged batch of k can reach), 1 context x 1 thread:")
+for k, (w, h) in ((2, (512, 256)), (4, (512, 512)), (8, (1024, 512)), (16, (1024, 1024))):
     ms, mp = bench([a], 1, w, h, max(4, FR // k))
     print("  k=%2d (%dx%d, %d tiles): %.2f ms per batch = %.2f ms per 256x256 image, %.1f Mpix/s" % (k, w, h, 4 * k, ms, ms / k, mp), flush=True)
 print("host -> host (pinned), 256x256:")
-for nthr in (1, 2, 4):
-    ms, mp = bench([a], nthr, 256, 256, FR, host=True)
-    print("  1 context x %d caller threads: %.2f ms per image, %.1f Mpix/s" % (nthr, ms, mp), flush=True)
+for merge in (1, 16):
+    a.set_option("merge", merge)
+    for nthr in (1, 4, 16):
+        ms, mp = bench([a], nthr, 256, 256, max(FR, 4 * nthr), host=True)
+        print("  merge=%2d, 1 context x %2d caller threads: %.2f ms per image, %.1f Mpix/s" % (merge, nthr, ms, mp), flush=True)
+print("other small geometries, merge=16, 16 threads (device-resident): ")
+for (w, h, T) in ((128, 128, 128), (200, 200, 200), (320, 240, 200), (512, 512, 200), (640, 480, 200)):
+    for merge in (1, 16):
+        a.set_option("merge", merge); a.tilesize = T
+        ms, mp = bench([a], 16, w, h, 64)
+        print("  %dx%d tile %d merge=%2d: %.2f ms per image, %.1f Mpix/s (merge width %d)" % (w, h, T, merge, ms, mp, a.get_stat("merged_widest")), flush=True)
 a.close()

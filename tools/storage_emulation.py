@@ -29,7 +29,8 @@ MODES = [
     ("fp32 trunk", {"trunk": "fp32", "fea16": False}),
     ("fp32 trunk + fp32 output", {"trunk": "fp32", "fea16": False, "out32": True}),
     ("fp32 at the 23 RRDB outputs only + fp32 output", {"trunk": "rrdb", "out32": True}),
-    ("ENGINE precise mode: hi/lo fp16 trunk, fea fp16, fp32 out", {"trunk": "split", "out32": True}),
+    ("hi + fp16 residue trunk, fp32 output", {"trunk": "split16", "fea16": False, "out32": True}),
+    ("ENGINE precise mode: hi + bf8 residue trunk, fp32 output", {"trunk": "split", "fea16": False, "out32": True}),
 ]
 
 

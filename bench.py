@@ -9,6 +9,8 @@
         bench.py --gpus N --steps K --warmup W          # the driver's own launch: WORLD_SIZE must equal N
     python bench.py --mode group --gpus N --frames F    # the PRODUCT's multi-GPU path in ONE process (config C4):
         rsr_create_group (weights by one RCCL broadcast) + jobs_proc threads per GPU on one shared frame queue
+    python bench.py --mode group --gpus 1 --frames 64 --frame-size 256x256 --tile 128 --jobs-proc 16
+        the reference's small-image mode ("-j 4:4:4 for many small images", README.md:61): concurrent calls are merged into one tile batch
 
 A "step" = one pass of the hot path (preproc -> 351 fused convs -> postproc over all 60 tiles) over one synthetic
 1920x1080 RGB frame per GPU.  One process per GPU; the only collective is the broadcast of the packed weights (RCCL) at
@@ -93,7 +95,7 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the newest tracked rocprofv3 PMC summary (tools/gpu_round.sh writes
     it: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md).  None when no such file is there."""
-    for name in ("r05_pmc_traffic.txt", "r04_pmc_traffic.txt", "r03_pmc_traffic.txt", "r02_pmc_traffic.txt"):
+    for name in ("r06_pmc_traffic.txt", "r05_pmc_traffic.txt", "r04_pmc_traffic.txt", "r03_pmc_traffic.txt", "r02_pmc_traffic.txt"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             txt = open(path).read()
@@ -105,7 +107,7 @@ def pmc_traffic():
     return None, None
 
 
-def cpu_baseline(pp, bp, gpu_c1=None):
+def cpu_baseline(pp, bp, gpu_c1=None, gpu_c1_precise=None):
     """CPU restatement (NOT ncnn: the reference's -g -1 path cannot be built here) on bounded samples of the workload:
     (1) the oracle, 16 OpenMP threads, one padded 220x220 tile of the C2 frame; (2) BASELINE config C1 AS STATED -- the whole
     256x256 frame at tile 128 through the oracle with one thread (~37 s); (3) PyTorch-CPU
@@ -121,8 +123,11 @@ def cpu_baseline(pp, bp, gpu_c1=None):
     out = net.process(img, 200)
     dt = time.time() - t
     threads = oracle.max_threads()
+    c2_px = padded_px(W_IN, H_IN, TILE, PREPAD)
     res = {"value": round(out.shape[0] * out.shape[1] / 1e6 / dt, 5), "unit": "Mpix/s", "cores": threads,
            "kind": "port", "host_cpus": os.cpu_count(),
+           # the C2 frame on these cores, EXTRAPOLATED from the one tile by padded pixels (60 tiles = 52.56 x the sample): not measured
+           "c2_extrapolated_ms": round(dt * 1e3 * c2_px / (220.0 * 220.0), 0), "c2_extrapolation": "tile seconds x 2,544,000 / 48,400 padded px",
            "sample": "oracle/realsr_oracle.c (CPU restatement of RealSR::process_cpu, not ncnn), one 200x200 "
                      "image at tile=200 = one padded 220x220 tile of the C2 frame, %.1f s, %.1f GFLOP/s" % (
                          dt, 220 * 220 * FLOP_PER_PADDED_LR_PX / dt / 1e9)}
@@ -140,6 +145,12 @@ def cpu_baseline(pp, bp, gpu_c1=None):
             "value": round(o1.shape[0] * o1.shape[1] / 1e6 / d1, 6), "unit": "Mpix/s", "cores": 1, "seconds": round(d1, 2),
             "checksum": int(o1[::97, ::89].astype("int64").sum()),
             "gpu_c1_max_abs_diff_uint8": (int(np.abs(o1.astype(np.int16) - gpu_c1.astype(np.int16)).max()) if gpu_c1 is not None and gpu_c1.shape == o1.shape else None),
+            "gpu_c1_bytes_differing_pct": (round(100.0 * float((o1 != gpu_c1).mean()), 3) if gpu_c1 is not None and gpu_c1.shape == o1.shape else None),
+            # the same frame with rsr_set_option("precise", 1): the residual trunk keeps a byte of rounding residue per element
+            "gpu_c1_precise_max_abs_diff_uint8": (int(np.abs(o1.astype(np.int16) - gpu_c1_precise.astype(np.int16)).max())
+                                                  if gpu_c1_precise is not None and gpu_c1_precise.shape == o1.shape else None),
+            "gpu_c1_precise_bytes_differing_pct": (round(100.0 * float((o1 != gpu_c1_precise).mean()), 3)
+                                                   if gpu_c1_precise is not None and gpu_c1_precise.shape == o1.shape else None),
             "sample": "measured: the whole C1 frame (models-DF2K_JPEG stand-in, 256x256 -> 1024x1024, tile 128 = four 148x148 padded tiles, "
                       "3.141 TFLOP) through the oracle with 1 thread, %.1f s, %.1f GFLOP/s (CPU restatement, not ncnn)" % (
                           d1, 4 * 148 * 148 * FLOP_PER_PADDED_LR_PX / d1 / 1e9)}
@@ -188,7 +199,7 @@ def board_gemm_ceiling(dev):
     return out
 
 
-def other_config(name, dev, w, h, T, tta, img_seed, model, wseed, steps=3, keep=None):
+def other_config(name, dev, w, h, T, tta, img_seed, model, wseed, steps=3, keep=None, precise=False):
     """A further single-GPU BASELINE config, device-resident like `value`: C1 (256x256, tile 128: the GPU side of the config the
     reference runs on its CPU path), C3 (3840x2160, tile 400), C5 (1080p, -x TTA).  keep: dict that receives the output frame."""
     import torch
@@ -199,6 +210,8 @@ def other_config(name, dev, w, h, T, tta, img_seed, model, wseed, steps=3, keep=
     try:
         sr.load(os.path.join(d, "x4.param"), os.path.join(d, "x4.bin"))
         sr.tilesize, sr.prepadding, sr.scale = T, PREPAD, SCALE
+        if precise:
+            sr.set_option("precise", 1)
         img = synth.make_image(img_seed, w, h)
         d_in = torch.from_numpy(img).to(dev)
         d_out = torch.empty((h * SCALE, w * SCALE, 3), dtype=torch.uint8, device=dev)
@@ -210,7 +223,7 @@ def other_config(name, dev, w, h, T, tta, img_seed, model, wseed, steps=3, keep=
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
         fl = padded_px(w, h, T, PREPAD) * FLOP_PER_PADDED_LR_PX * (8 if tta else 1)
-        res = {"config": "%s, %dx%d, tile %d%s, 1 GPU, device-resident" % (model, w, h, T, ", TTA x8 (-x)" if tta else ""),
+        res = {"config": "%s, %dx%d, tile %d%s%s, 1 GPU, device-resident" % (model, w, h, T, ", TTA x8 (-x)" if tta else "", ", precise mode" if precise else ""),
                "ms_per_frame": round(dt * 1e3, 2), "value": round(16.0 * w * h / 1e6 / dt, 2), "unit": "Mpix/s", "steps": steps,
                "frame_tflop": round(fl / 1e12, 3), "frac_of_peak": round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
                "frac_of_peak_executed": round(executed_flop(w, h, T, PREPAD, tta) / dt / 1e12 / PEAK_F16_TFLOPS, 4),
@@ -259,20 +272,33 @@ def group_mode(args):
     else:
         srs, transport = R.create_group(list(range(n)), pp, bp)
     load_s = time.perf_counter() - t0
+    GW, GH = (int(v) for v in args.frame_size.lower().split("x"))
+    GT = args.tile
     for s in srs:
-        s.tilesize, s.prepadding, s.scale = TILE, PREPAD, SCALE
+        s.tilesize, s.prepadding, s.scale = GT, PREPAD, SCALE
         s._push_params()
+        if args.merge is not None:
+            s.set_option("merge", args.merge)
+        s.set_option("max_lanes", max(16, args.jobs_proc))
     frames = args.frames
     jobs = args.jobs_proc
-    src = [synth.make_image(1235 + i, W_IN, H_IN) for i in range(min(frames, 4))]
+    src = [synth.make_image(1235 + i, GW, GH) for i in range(min(frames, 4))]
     pin_in = []
     for im in src:
         p = R.PinnedArray(im.shape)
         p.array[:] = im
         pin_in.append(p)
-    outs = [[R.PinnedArray((H_IN * SCALE, W_IN * SCALE, 3)) for _ in range(jobs)] for _ in srs]
-    for gi, s in enumerate(srs):  # warm-up: plans, workspaces, lanes
+    outs = [[R.PinnedArray((GH * SCALE, GW * SCALE, 3)) for _ in range(jobs)] for _ in srs]
+    for gi, s in enumerate(srs):  # warm-up: plans, workspaces
         s.process(pin_in[0].array, out=outs[gi][0].array, push_params=False)
+    # ... and the lanes of every proc thread (stream, events, device buffers, pinned staging are created on a thread's first call)
+    wth = [threading.Thread(target=lambda gi=gi, ji=ji: srs[gi].process(pin_in[0].array, out=outs[gi][ji].array, push_params=False))
+           for gi in range(len(srs)) for ji in range(jobs)]
+    for t in wth:
+        t.start()
+    for t in wth:
+        t.join()
+    merged0 = [(s.get_stat("merged_batches"), s.get_stat("merged_images")) for s in srs]
     lock = threading.Lock()
     nxt = [0]
     done = [[0] * jobs for _ in srs]
@@ -298,7 +324,7 @@ def group_mode(args):
         t.join()
     dt = time.perf_counter() - t1
     # one large image over all contexts, tiles dealt by rsr_process_group
-    big_out = R.PinnedArray((H_IN * SCALE, W_IN * SCALE, 3))
+    big_out = R.PinnedArray((GH * SCALE, GW * SCALE, 3))
     R.process_group(srs, pin_in[0].array, out=big_out.array)
     t2 = time.perf_counter()
     reps = 3
@@ -306,15 +332,21 @@ def group_mode(args):
         R.process_group(srs, pin_in[0].array, out=big_out.array)
     dt_one = (time.perf_counter() - t2) / reps
     one_ok = int(big_out.array[::97, ::89].astype(np.int64).sum()) == sums.get(0)
-    out_mpix = W_IN * SCALE * H_IN * SCALE / 1e6
-    res = {"metric": "output Mpix/s (4x upscale) DF2K tile=200", "mode": "group", "value": round(out_mpix * frames / dt, 3), "unit": "Mpix/s",
+    out_mpix = GW * SCALE * GH * SCALE / 1e6
+    mb = sum(s.get_stat("merged_batches") - m[0] for s, m in zip(srs, merged0))
+    mi = sum(s.get_stat("merged_images") - m[1] for s, m in zip(srs, merged0))
+    res = {"metric": "output Mpix/s (4x upscale) DF2K tile=%d" % GT, "mode": "group", "value": round(out_mpix * frames / dt, 3), "unit": "Mpix/s",
            "n_gpus": n, "frames": frames, "seconds": round(dt, 3), "higher_is_better": True, "scaling": "strong", "dtype": "f16", "data": "synthetic",
-           "config": {"workload": "C4: %d x (1920x1080 -> 7680x4320) frames, models-DF2K, tile 200, host memory -> host memory (pinned), "
-                                  "%d GPUs x jobs_proc %d threads on one shared queue (main.cpp:811-828)" % (frames, n, jobs),
+           # small images of concurrent calls walk the network as one tile batch (engine.h): how many did
+           "merged": {"images": int(mi), "batches": int(mb), "images_per_batch": round(mi / mb, 2) if mb else None,
+                      "merge_option": args.merge if args.merge is not None else 16},
+           "config": {"workload": "%s%d x (%dx%d -> %dx%d) frames, models-DF2K, tile %d, host memory -> host memory (pinned), "
+                                  "%d GPUs x jobs_proc %d threads on one shared queue (main.cpp:811-828)" % (
+                                      "C4: " if (GW, GH, GT) == (1920, 1080, 200) else "", frames, GW, GH, GW * SCALE, GH * SCALE, GT, n, jobs),
                       "parallelism": "one process, rsr_create_group: weights by %s; frames from a shared queue, no data-path collective" % transport,
                       "group_transport": transport, "group_members": len(srs), "visible_devices": have, "load_seconds": round(load_s, 3),
                       "frames_per_gpu": [sum(x) for x in done]},
-           "single_image_over_group": {"what": "ONE C2 frame, its 60 tiles dealt over the %d contexts by rsr_process_group (host -> host)" % n,
+           "single_image_over_group": {"what": "ONE frame, its tiles dealt over the %d contexts by rsr_process_group (host -> host)" % n,
                                        "ms": round(dt_one * 1e3, 2), "value": round(out_mpix / dt_one, 2), "unit": "Mpix/s",
                                        "bytes_equal_single_context": bool(one_ok)}}
     print(json.dumps(res), flush=True)
@@ -332,6 +364,9 @@ def main():
     ap.add_argument("--mode", choices=("ranks", "group"), default="ranks")
     ap.add_argument("--frames", type=int, default=64, help="group mode: frames in the queue (C4: 64)")
     ap.add_argument("--jobs-proc", type=int, default=2, help="group mode: proc threads per GPU (the reference's default, main.cpp:708-711)")
+    ap.add_argument("--frame-size", default="%dx%d" % (W_IN, H_IN), help="group mode: WxH of the frames (default the C2 / C4 frame)")
+    ap.add_argument("--tile", type=int, default=TILE, help="group mode: tile size")
+    ap.add_argument("--merge", type=int, default=None, help="group mode: rsr_set_option merge (1 = small images of concurrent calls are not merged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-host", action="store_true", help="skip the host->host leg")
@@ -535,9 +570,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "value_definition": "images resident in HBM when the timed region starts (rsr_process_device) -- the bench contract of this tier: 'inputs "
-                                "already resident in HBM when the timed region starts; a PCIe-inclusive rate is never `value`'.  SURVEY 8(d)'s end-user "
-                                "metric (host memory -> host memory, rsr_process) is `host_to_host_pinned` right below, details in `host_to_host`",
+            "value_definition": "HBM-resident images (rsr_process_device; the bench contract); SURVEY 8(d)'s metric, host memory -> host memory, is `host_to_host_pinned`",
             "device_resident": round(out_mpix * world * args.steps / dt, 3),
             "host_to_host_pinned": round(out_mpix * world * args.steps / host["pinned"], 3) if host else None,
             "config": {
@@ -678,12 +711,25 @@ def main():
                 res["other_configs"][name] = other_config(name, dev, *cfg, steps=steps, keep=kept if name == "C1" else None)
             except Exception as e:  # noqa: BLE001 -- never lose the C2 line over a side leg
                 res["other_configs"][name] = {"value": None, "error": repr(e)}
+        # PRECISE mode (rsr_set_option precise 1: the residual trunk keeps a byte of rounding residue per element, conv_last's fp32 result goes to
+        # uint8 unrounded): C2 and C1 again -- what half the distance to the fp32 CPU path costs
+        res["precise_mode"] = {"what": "the same engine with option precise = 1 (default 0 = fp16 storage, the reference GPU path's own, realsr.cpp:44-46)"}
+        for name, cfg, steps in (("C2", (W_IN, H_IN, TILE, False, 1235, "models-DF2K", 42), args.steps),
+                                 ("C1", (256, 256, 128, False, 1234, "models-DF2K_JPEG", 43), 20)):
+            try:
+                res["precise_mode"][name] = other_config(name + "p", dev, *cfg, steps=steps, keep=kept if name == "C1" else None, precise=True)
+            except Exception as e:  # noqa: BLE001
+                res["precise_mode"][name] = {"value": None, "error": repr(e)}
+        try:
+            res["precise_mode"]["c2_cost_pct"] = round(100.0 * (res["precise_mode"]["C2"]["ms_per_frame"] / res["ms_per_step"] - 1.0), 2)
+        except Exception:  # noqa: BLE001
+            pass
         res["other_configs"]["C4"] = {"value": None, "status": "unmeasured: n_gpus = 1",
                                       "config": "64 x C2 frames over 8 GPUs, -j 4:8:4 (one process, rsr_create_group, proc threads on one shared queue)",
                                       "n1_anchor": "group_mode below: the same pipeline with ONE GPU, 16 frames, jobs_proc 2, host -> host"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(pp, bp, gpu_c1=kept.get("C1"))
+            res["cpu_baseline"] = cpu_baseline(pp, bp, gpu_c1=kept.get("C1"), gpu_c1_precise=kept.get("C1p"))
         except Exception as e:  # the oracle is optional here; never fail the GPU number on it
             res["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0 and world == 1 and not same_gpu and not args.no_group:
@@ -697,6 +743,21 @@ def main():
             res["group_mode"] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"value": None, "error": "rc %d: %s" % (r.returncode, r.stderr[-600:])}
         except Exception as e:  # noqa: BLE001
             res["group_mode"] = {"value": None, "error": repr(e)}
+        # The reference's small-image mode (README.md:61 "-j 4:4:4 for many small images"; main.cpp:811-828): 64 frames of 256 x 256 at tile 128
+        # (the C1 geometry) from 16 proc threads on one context, host -> host.  Concurrent calls are merged into one tile batch; the same
+        # run with merging off (the calls queue up on the one compute stream) beside it.
+        res["small_images"] = {}
+        for key, merge in (("merged", "16"), ("not_merged", "1")):
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", "group", "--gpus", "1", "--frames", "64", "--frame-size", "256x256",
+                   "--tile", "128", "--jobs-proc", "16", "--merge", merge]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                j = json.loads(lines[-1]) if (r.returncode == 0 and lines) else None
+                res["small_images"][key] = ({"value": j["value"], "unit": "Mpix/s", "frames": j["frames"], "seconds": j["seconds"], "merged": j["merged"],
+                                             "workload": j["config"]["workload"]} if j else {"value": None, "error": "rc %d: %s" % (r.returncode, r.stderr[-400:])})
+            except Exception as e:  # noqa: BLE001
+                res["small_images"][key] = {"value": None, "error": repr(e)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

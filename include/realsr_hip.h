@@ -73,7 +73,9 @@ int rsr_process(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* o
 /* Same computation with both images already resident in this context's device memory
  * (what the reference keeps in VkMat in_gpu/out_gpu, realsr.cpp:211-233, minus the PCIe hops).
  * `stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous when a stream is
- * given: the caller synchronises. */
+ * given: the caller synchronises.  When nothing else is in flight on the context the kernels are
+ * enqueued on `stream` itself; otherwise they run on the context's compute stream, ordered behind
+ * the work already on `stream` and in front of what the caller enqueues on it next. */
 int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void* d_out, void* stream);
 
 /* Pinned host memory for images.  rsr_process copies pinned buffers (these, hipHostMalloc'd or hipHostRegister'ed

@@ -386,6 +386,7 @@ int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value)
     else if (k == "lane_out_mb") *value = lanes_bytes(true) / 1048576.0;
     else if (k == "lane_in_mb") *value = lanes_bytes(false) / 1048576.0;
     else if (k == "last_test_us") *value = e.last_test_us;
+    else if (k == "device_direct") *value = double(e.device_direct);
     else if (k == "merged_batches") *value = double(e.merged_batches.load());
     else if (k == "merged_images") *value = double(e.merged_images.load());
     else if (k == "merged_widest") *value = double(e.merged_widest.load());

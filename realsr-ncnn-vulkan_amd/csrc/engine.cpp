@@ -2,7 +2,9 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace rsr {
@@ -892,6 +894,7 @@ int Engine::enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hi
 int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg, int w, int h, int c, hipStream_t st, int tile0, int tile1,
                            hipEvent_t ev_half, size_t* half_rows, hipEvent_t ev_mid, int plan_nimg)
 {
+    const bool merged = plan_nimg > 0; // (every caller of a merged batch reports the progress of its own image: process_host)
     if (plan_nimg < nimg) plan_nimg = nimg;
     const long long kBytesPerPx = bytes_per_px();
     if (half_rows) *half_rows = 0;
@@ -1002,7 +1005,7 @@ int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg
         rc = run_network(b, st, fused ? outs : nullptr, nimg, w * scale, split_slot, ev_half, last_batch ? ev_mid : nullptr,
                          kNumRDB - 1 - std::max(2, kNumRDB / (2 * std::max(1, nimg))), nslots_used);
         if (rc != RSR_OK) return rc;
-        if (progress && nimg == 1) // one call per TILE, like the reference's line per tile (realsr.cpp:481), issued when the tile's batch is enqueued
+        if (progress && !merged) // one call per TILE, like the reference's line per tile (realsr.cpp:481), issued when the tile's batch is enqueued
             for (int i = 1; i <= b.ntiles; i++) progress(done + i, total, progress_user); // (a merged batch: every caller reports its own image)
         done += b.ntiles;
         if (fused) continue;
@@ -1069,6 +1072,24 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
         if (!loaded) return fail(RSR_E_STATE, "process before load");
         if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
         HIP_TRY(hipSetDevice(device));
+        if (user_stream && hipStreamQuery(stream) == hipSuccess)
+        {
+            // The engine is idle -- nothing of any earlier call is pending on the compute stream (work an earlier call of this kind
+            // put on ITS caller's stream included: the compute stream was made to wait for it, below) -- so this call's kernels go
+            // straight onto the caller's stream: no event hop into the compute stream and back.  Whatever is enqueued on the compute
+            // stream later uses the same workspace and must come behind: it waits for this call's last kernel.
+            const int rc = enqueue_image(d_in, w, h, c, d_out, user_stream);
+            hipEvent_t e = take_event();
+            if (!e || hipEventRecord(e, user_stream) != hipSuccess || hipStreamWaitEvent(stream, e, 0) != hipSuccess)
+            { // cannot order the compute stream behind it: fall back to waiting here
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(user_stream);
+            }
+            give_event(e);
+            if (rc == RSR_OK) device_direct++;
+            return rc;
+        }
+        (void)hipGetLastError(); // (hipErrorNotReady is not an error)
         // All network kernels run on the engine's compute stream (one workspace); a caller stream is ordered around them.
         if (user_stream)
         {
@@ -1186,6 +1207,7 @@ int Engine::submit_merged(MergeReq& r)
 {
     std::unique_lock<std::mutex> lk(cq_mu);
     cq.push_back(&r);
+    cq_cv.notify_all(); // (a leader may be waiting for the calls it knows to be inbound)
     if (cq_leader)
     {
         cq_cv.wait(lk, [&]() { return r.done || r.lead; });
@@ -1208,6 +1230,10 @@ int Engine::submit_merged(MergeReq& r)
         lk.unlock();
         if (wait_ev) (void)hipEventSynchronize(wait_ev);
         lk.lock();
+        // Calls that are known to be on their way (their image is still being uploaded) are worth a moment: a batch costs milliseconds,
+        // they arrive within microseconds -- 16 callers that start together would otherwise open with batches of 1, 1, 7, 7.
+        for (int spins = 0; merge_inbound.load() > 0 && int(cq.size()) < kMaxMerge && spins < 8; spins++)
+            cq_cv.wait_for(lk, std::chrono::microseconds(50));
         MergeReq* g[kMaxMerge];
         int n = 0;
         const MergeReq* head = cq.front();
@@ -1222,6 +1248,11 @@ int Engine::submit_merged(MergeReq& r)
         if (merge_last_n > 0 && merge_done && hipEventQuery(merge_done) == hipErrorNotReady) take = std::min(n, std::max(1, (n + merge_last_n + 1) / 2));
         (void)hipGetLastError(); // (hipErrorNotReady is not an error)
         for (int i = 0; i < take; i++) cq.erase(std::find(cq.begin(), cq.end(), g[i]));
+        static const bool trace = std::getenv("RSR_MERGE_TRACE") != nullptr; // (debug aid: one line per merged batch)
+        if (trace)
+            std::fprintf(stderr, "merge: t=%.3f ms take %d of %d waiting (width %d, previous batch of %d %s, %d inbound)\n",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), take, n, width, merge_last_n,
+                         (merge_done && hipEventQuery(merge_done) == hipErrorNotReady) ? "running" : "done", merge_inbound.load());
         lk.unlock();
         const int rc = run_group(g, take);
         const std::string why = rc == RSR_OK ? std::string() : std::string(last_error());
@@ -1321,6 +1352,20 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     const int xtiles = (w + T - 1) / T, ytiles = (h + T - 1) / T;
     if (tile1 < 0) tile1 = xtiles * ytiles;
     if (tile0 < 0 || tile1 > xtiles * ytiles || tile0 >= tile1) return fail(RSR_E_ARG, "tile range outside the image");
+    // a small whole image is merged with the images other callers hand in meanwhile (Engine::submit_merged); a leader that is
+    // forming a batch gives the calls counted here a moment to finish their upload
+    const bool mergeable = tile0 == 0 && tile1 == xtiles * ytiles && merge_width(w, h, c) > 1;
+    struct Inbound
+    {
+        std::atomic<int>* n;
+        ~Inbound() { release(); }
+        void release()
+        {
+            if (n) --*n;
+            n = nullptr;
+        }
+    } inbound{mergeable ? &merge_inbound : nullptr};
+    if (mergeable) ++merge_inbound;
     Lane* L = acquire_lane();
     // Whatever way this call ends, nothing of it may still be in flight when the lane -- and with it the caller's `in` / `out`
     // -- is handed back: a HIP failure half way must not turn into a use-after-free of the lane buffers by the next caller.
@@ -1373,12 +1418,13 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
 
     // ---- network ----
     size_t half_rows = 0;
-    if (tile0 == 0 && tile1 == xtiles * ytiles && merge_width(w, h, c) > 1)
-    { // a small whole image: merged with the images other callers hand in meanwhile (Engine::submit_merged)
+    if (mergeable)
+    {
         MergeReq r;
         r.d_in = L->d_in.p; r.d_out = dbase; r.w = w; r.h = h; r.c = c; r.T = T;
         r.ev_in = L->ev_in;
         r.ev_done = L->ev_done;
+        inbound.release(); // (it is in the queue the moment submit_merged has the lock: the leader's wait ends either way)
         rc = submit_merged(r);
         if (rc != RSR_OK) return rc; // (a batch that failed half way has been drained by its leader: nothing of it is in flight)
         guard.done_recorded = true;

@@ -196,6 +196,8 @@ struct Engine
     hipEvent_t merge_done = nullptr; // ... and behind it
     int merge_last_n = 0;            // images in that batch
     std::atomic<long long> merged_batches{0}, merged_images{0}, merged_widest{0}; // stats
+    std::atomic<int> merge_inbound{0}; // calls with a small image that are on their way to submit_merged (uploading): a leader waits a moment for them
+    long long device_direct = 0; // rsr_process_device calls that ran on the caller's own stream (the engine was idle), under mu
     int merge_width(int w, int h, int c) const; // images of this geometry one batch may take (1: not a small image / merging off)
     int submit_merged(MergeReq& r);             // returns when r's batch has been ENQUEUED (r.ev_done recorded) or failed
     int run_group(MergeReq* const* g, int n);   // mu inside

@@ -329,6 +329,25 @@ def test_device_api_equals_host_api(sr):
     sr.process_device(d_in.data_ptr(), 61, 47, 3, d_out.data_ptr())
     torch.cuda.synchronize()
     assert (d_out.cpu().numpy() == host).all()
+    # On a caller's (non-default) stream, asynchronously.  The first call finds the context idle and runs ON that stream (no hop through
+    # the context's compute stream: stat device_direct); the second, issued right behind it, finds work pending -- the compute stream
+    # waits for the first -- and takes the ordered path through the compute stream.  Same bytes both ways; work the caller enqueues on
+    # its stream afterwards (the copy below) sees the finished image.
+    st = torch.cuda.Stream()
+    outs = [torch.zeros_like(d_out) for _ in range(3)]
+    n0 = sr.get_stat("device_direct")
+    with torch.cuda.stream(st):
+        for o in outs:
+            sr.process_device(d_in.data_ptr(), 61, 47, 3, o.data_ptr(), stream=st.cuda_stream)
+        copies = [o.clone() for o in outs]
+    st.synchronize()
+    assert sr.get_stat("device_direct") - n0 >= 1
+    for o in copies:
+        assert (o.cpu().numpy() == host).all()
+    torch.cuda.synchronize()
+    sr.process_device(d_in.data_ptr(), 61, 47, 3, outs[0].data_ptr(), stream=st.cuda_stream)  # idle again: direct
+    st.synchronize()
+    assert sr.get_stat("device_direct") - n0 >= 2 and (outs[0].cpu().numpy() == host).all()
 
 
 def test_packed_blob_load_equals_file_load(paths, sr):

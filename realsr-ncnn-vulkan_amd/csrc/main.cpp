@@ -330,6 +330,17 @@ int main(int argc, char** argv)
         // the reference prints one line per tile, "%.2f%%" of (yi * xtiles + xi) / (ytiles * xtiles) (realsr.cpp:481): the same lines
         // here, one per tile of every batch (a batch of tiles runs at once, so they arrive in bursts)
         rsr_set_progress_callback(ctxs[size_t(i)], [](int done, int total, void*) { fprintf(stderr, "%.2f%%\n", total ? 100.f * float(done - 1) / float(total) : 0.f); }, nullptr);
+        // every proc thread of this GPU may have a call in flight (small images of concurrent calls are merged into one tile batch: the
+        // reference's "-j 4:4:4 for many small images", README.md:61 -- here the more proc threads, the fuller the launches)
+        rsr_set_option(ctxs[size_t(i)], "max_lanes", std::max(16, std::min(64, jobs_proc[size_t(i)])));
+        // no flag of the reference's surface is taken for it: RSR_PRECISE=1 keeps a byte of rounding residue per element of the residual
+        // trunk (rsr_set_option "precise"; what tools/check_real_model.py recommends for weights with a wide output swing)
+        if (const char* pe = getenv("RSR_PRECISE"))
+            if (pe[0] && pe[0] != '0')
+            {
+                rsr_set_option(ctxs[size_t(i)], "precise", 1);
+                if (verbose) fprintf(stderr, "gpu %d: precise residual trunk (RSR_PRECISE)\n", gpuid[size_t(i)]);
+            }
         realsr.push_back(std::move(r));
     }
     // one image, several GPUs: every GPU takes a share of the tile rows

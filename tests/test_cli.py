@@ -234,6 +234,43 @@ def test_cli_directory_run_matches_library(tmp_path, model_dir):
 
 
 @pytest.mark.gpu
+def test_cli_many_small_images_and_precise_mode(tmp_path, model_dir):
+    """The reference's small-image mode ("-j 4:4:4 for many small images", README.md:61): 24 same-size pngs through -j 2:8:2 -- eight proc
+    threads call the one context concurrently, their images are merged into shared tile batches (engine.h) -- every output byte equal
+    to a lone library call's; progress lines still one per tile and image (realsr.cpp:481).  The same directory with RSR_PRECISE=1 in the
+    environment equals the library with rsr_set_option("precise", 1)."""
+    ind, outd, outp = tmp_path / "in", tmp_path / "out", tmp_path / "outp"
+    for d in (ind, outd, outp):
+        d.mkdir()
+    imgs = {"s%02d.png" % i: synth.make_image(500 + i, 48, 40) for i in range(24)}
+    for name, im in imgs.items():
+        write_png(ind / name, im)
+    sr = R.RealSR(0)
+    sr.load(os.path.join(model_dir, "x4.param"), os.path.join(model_dir, "x4.bin"))
+    sr.tilesize = 32
+    sr.set_option("merge", 1)
+    want = {n: sr.process(im) for n, im in imgs.items()}
+    sr.set_option("precise", 1)
+    wantp = {n: sr.process(im) for n, im in imgs.items()}
+    sr.close()
+    r = run_cli("-i", str(ind), "-o", str(outd), "-m", model_dir, "-t", "32", "-j", "2:8:2")
+    assert r.returncode == 0, r.stderr
+    lines = r.stderr.splitlines()
+    assert lines.count("0.00%") == 24 and lines.count("25.00%") == 24 and lines.count("75.00%") == 24, r.stderr[-2000:]  # 48x40 at tile 32 = 2 x 2 tiles
+    for n in imgs:
+        assert (read_png(outd / n) == want[n]).all(), n
+    rp = subprocess.run([CLI, "-i", str(ind), "-o", str(outp), "-m", model_dir, "-t", "32", "-j", "2:8:2", "-v"], capture_output=True, text=True,
+                        env=dict(os.environ, RSR_PRECISE="1"))
+    assert rp.returncode == 0 and "precise residual trunk" in rp.stderr, rp.stderr[-2000:]
+    differs = 0
+    for n in imgs:
+        got = read_png(outp / n)
+        assert (got == wantp[n]).all(), n
+        differs += int((got != want[n]).any())
+    assert differs > 0  # (and precise mode is not the default mode by another name)
+
+
+@pytest.mark.gpu
 def test_cli_jpg_directory_and_threads(tmp_path, model_dir):
     """-j 2:4:2 over a directory of jpg + RGBA png inputs, jpg output: 4 proc threads share one context (main.cpp:811-828);
     the RGBA image cannot be a jpg and is written as <name>.jpg.png (main.cpp:278-288).  The png outputs equal the library

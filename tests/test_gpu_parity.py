@@ -216,9 +216,11 @@ def test_postproc_tta_kernel(sr):
 
 # ---- network on one tile ------------------------------------------------------------------------------
 def test_network_tile_prequantise_error(sr, oracle_net):
-    """Pre-quantise error of the `output` blob in [0,1] units.  Stated tolerance: max <= 4e-3,
-    p99.9 <= 2e-3 (fp16 storage / fp32 accumulate -- the reference Vulkan path's arithmetic, realsr.cpp:44-46 -- vs fp32
-    everywhere, 351 convs); uint8 +-1."""
+    """Pre-quantise error of the `output` blob in [0,1] units, fp16 storage (the default).  Stated tolerance: max <= 3.0e-3 -- below one
+    uint8 step, 1/255 = 3.92e-3, with margin, so that it IMPLIES the +-1 bar -- and p99.9 <= 1.5e-3 (fp16 storage / fp32 accumulate --
+    the reference Vulkan path's arithmetic, realsr.cpp:44-46 -- vs fp32 everywhere, 351 convs; measured 1.6 - 2.1e-3 / 0.9 - 1.1e-3 on the
+    stand-ins).  SURVEY 8(c)'s target of 2e-3 / 5e-4 is NOT met by fp16 storage (the trunk is rounded 92 times on its way through the
+    RRDBs); precise mode meets it: tests/test_gpu_precise.py.  uint8 +-1."""
     img = synth.make_image(5, 44, 36)
     x = (img.astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)).astype(np.float16)
     ref = oracle_net.forward(x.astype(np.float32))
@@ -229,7 +231,7 @@ def test_network_tile_prequantise_error(sr, oracle_net):
             got = sr.net_forward(x).astype(np.float32)
             d = np.abs(got - ref)
             print("flow_flags=%d max %.3e p99.9 %.3e mean %.3e" % (flags, d.max(), np.quantile(d, 0.999), d.mean()))
-            assert d.max() <= 4e-3 and np.quantile(d, 0.999) <= 2e-3
+            assert d.max() <= 3.0e-3 and np.quantile(d, 0.999) <= 1.5e-3
             assert np.abs(q(got) - q(ref)).max() <= 1
     finally:
         sr.set_option("flow_flags", 0)

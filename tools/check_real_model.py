@@ -11,7 +11,8 @@ parses, validates the graph, packs the blob, reports weight statistics (max |w|,
 (3) walks the network in fp32 on the CPU oracle over a real-image-like tile and reports the ACTIVATION RANGE per RDB -- the
 engine stores every feature map as fp16 (max 65504): the overflow guard for weights nobody has run through it before; (4) on
 the GPU: BASELINE C1 (256x256, tile 128) whole frame against the oracle, +-1 uint8, the pre-quantise error (max / p99.9, the
-tolerances of tests/test_gpu_parity.py: 4e-3 / 2e-3), and (5) the C2 bench leg (1080p, tile 200, device-resident, 5 steps).
+tolerances of tests/test_gpu_parity.py: 3.0e-3 / 1.5e-3 with fp16 storage; when the headroom of the +-1 bar is below 1.5 the harness
+switches to precise mode -- rsr_set_option precise 1 -- and says so), and (5) the C2 bench leg (1080p, tile 200, device-resident, 5 steps).
 
 Exit status: 0 = every check that could run passed, or nothing to check (no blob: prints SKIP); 1 = a check failed.
 The oracle is the checker here, as in tests/ -- this is test infrastructure, not a product path.
@@ -134,19 +135,24 @@ def gpu_checks(pp, bp, net, rep, bench):
     ok = True
     sr = R.RealSR(0)
     sr.load(pp, bp)
-    # pre-quantise, one 148 x 148 padded tile of the C1 frame
+    # pre-quantise, one 148 x 148 padded tile of the C1 frame.  Tolerances (one uint8 step is 1/255 = 3.92e-3):
+    #   fp16 storage (the engine's default = the reference GPU path's own storage, realsr.cpp:44-46):  max <= 3.0e-3, p99.9 <= 1.5e-3
+    #   precise mode (rsr_set_option precise 1):  max <= 2.6e-3 (a headroom of 1.5 on the +-1 bar); on the stand-ins it meets SURVEY 8(c)'s
+    #   2e-3 / 5e-4 (tests/test_gpu_precise.py)
+    # The harness measures fp16 storage first; when its headroom (one step / max error) is below 1.5 -- or a tolerance is missed -- it
+    # switches the engine to precise mode, measures again, and runs the C1 and bench legs in the mode it RECOMMENDS for these weights.
     img = synth.make_image(1234, 256, 256)
     big = np.pad(img, ((10, 10), (10, 10), (0, 0)), mode="reflect")
     x = (big[:148, :148, :3].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)).astype(np.float16)
     got = sr.net_forward(x).astype(np.float32)
     ref = net.forward(x.astype(np.float32))
     e = np.abs(got - ref)
-    rep["pre_quantise"] = {"max": float(e.max()), "p99_9": float(np.quantile(e, 0.999)), "nan_or_inf": bool(~np.isfinite(got).all())}
-    print("  network output before quantisation, engine vs oracle on one 148x148 tile ([0,1] units): max %.3e  p99.9 %.3e  (tolerance 4e-3 / 2e-3)" % (
-        e.max(), np.quantile(e, 0.999)))
-    if not np.isfinite(got).all() or e.max() > 4e-3 or np.quantile(e, 0.999) > 2e-3:
-        print("  FAIL: pre-quantise error outside the stated tolerance")
-        ok = False
+    step = 1.0 / 255.0
+    head16 = step / max(float(e.max()), 1e-12)
+    rep["pre_quantise"] = {"max": float(e.max()), "p99_9": float(np.quantile(e, 0.999)), "nan_or_inf": bool(~np.isfinite(got).all()), "headroom": head16}
+    print("  network output before quantisation, fp16 storage (default), engine vs oracle on one 148x148 tile ([0,1] units): max %.3e  p99.9 %.3e  "
+          "(tolerance 3.0e-3 / 1.5e-3); headroom of the +-1 uint8 bar = one step (3.92e-3) / max = %.2f" % (e.max(), np.quantile(e, 0.999), head16))
+    ok16 = bool(np.isfinite(got).all() and e.max() <= 3.0e-3 and np.quantile(e, 0.999) <= 1.5e-3)
     # Is that error the engine's arithmetic or the fp16 STORAGE format (which the reference's Vulkan path shares, realsr.cpp:44-46)?
     # A PyTorch-CPU emulation of fp16 storage / fp32 arithmetic on the same tile must deviate from the fp32 oracle by the same amount.
     try:
@@ -159,13 +165,27 @@ def gpu_checks(pp, bp, net, rep, bench):
                                          "engine_vs_oracle_mean": float(e.mean()), "engine_vs_emulation_mean": float(ex.mean())}
         print("  fp16-storage emulation (PyTorch CPU) vs oracle on that tile: max %.3e  p99.9 %.3e  mean %.3e;  engine vs oracle mean %.3e;  engine vs emulation mean %.3e" % (
             ee.max(), np.quantile(ee, 0.999), ee.mean(), e.mean(), ex.mean()))
-        print("  headroom of the +-1 uint8 bar: one step (1/255 = 3.92e-3) / max pre-quantise error = %.2f (below ~1 single bytes may differ by 2 from the fp32 CPU path: the storage format, not a defect)" % (
-            (1.0 / 255.0) / max(float(e.max()), 1e-12)))
         if abs(e.mean() / max(ee.mean(), 1e-12) - 1) > 0.15:
             print("  FAIL: the engine's deviation from the oracle is not what fp16 storage alone explains (mean error differs from the emulation's by > 15 %)")
             ok = False
     except Exception as ex_:  # noqa: BLE001 -- a diagnostic, never the reason the harness dies
         print("  (fp16-storage emulation skipped: %r)" % (ex_,))
+    rep["recommended_mode"] = "default"
+    if not ok16 or head16 < 1.5:
+        print("  fp16 storage leaves a headroom below 1.5 on these weights%s: switching to PRECISE mode (rsr_set_option precise 1; CLI: RSR_PRECISE=1)" % (
+            "" if ok16 else " and misses the stated tolerance"))
+        sr.set_option("precise", 1)
+        got = sr.net_forward_f32(x)
+        e = np.abs(got - ref)
+        headp = step / max(float(e.max()), 1e-12)
+        rep["pre_quantise_precise"] = {"max": float(e.max()), "p99_9": float(np.quantile(e, 0.999)), "nan_or_inf": bool(~np.isfinite(got).all()), "headroom": headp}
+        print("  network output before quantisation, precise mode: max %.3e  p99.9 %.3e  (tolerance max 2.6e-3); headroom %.2f" % (e.max(), np.quantile(e, 0.999), headp))
+        if not np.isfinite(got).all() or e.max() > 2.6e-3:
+            print("  FAIL: pre-quantise error outside the stated tolerance in precise mode too -- fp16 operands cannot hold +-1 against the fp32 CPU path on these weights")
+            ok = False
+        else:
+            rep["recommended_mode"] = "precise"
+    print("  recommended mode for these weights: %s" % rep["recommended_mode"])
     # C1: whole frame, tile 128, +-1 uint8
     sr.tilesize = 128
     t = time.time()
@@ -176,8 +196,8 @@ def gpu_checks(pp, bp, net, rep, bench):
     t_cpu = time.time() - t
     d = np.abs(out.astype(int) - want.astype(int))
     rep["c1"] = {"max_diff": int(d.max()), "frac_differ": float((d > 0).mean()), "frac_gt1": float((d > 1).mean()), "gpu_s_first_call": t_gpu, "oracle_s": t_cpu}
-    print("  C1 (256x256, tile 128, 4 tiles) engine vs oracle: max |d| = %d, %.2f %% of the bytes differ, %.4f %% by more than 1   (oracle %.1f s)" % (
-        d.max(), 100 * (d > 0).mean(), 100 * (d > 1).mean(), t_cpu))
+    print("  C1 (256x256, tile 128, 4 tiles) engine (%s mode) vs oracle: max |d| = %d, %.2f %% of the bytes differ, %.4f %% by more than 1   (oracle %.1f s)" % (
+        rep["recommended_mode"], d.max(), 100 * (d > 0).mean(), 100 * (d > 1).mean(), t_cpu))
     if d.max() > 1:
         print("  FAIL: C1 outside +-1")
         ok = False

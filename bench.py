@@ -228,6 +228,10 @@ def other_config(name, dev, w, h, T, tta, img_seed, model, wseed, steps=3, keep=
                "frame_tflop": round(fl / 1e12, 3), "frac_of_peak": round(fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
                "frac_of_peak_executed": round(executed_flop(w, h, T, PREPAD, tta) / dt / 1e12 / PEAK_F16_TFLOPS, 4),
                "tile_batches": int(sr.get_stat("plan_batches")),
+               # the engine's own count of 16 x 32 blocks per level (x 512 px x the level's FLOP per px): an upper bound of the executed
+               # matrix work (MFMA waves still skip rows below the tile); the model above is held against it
+               "frac_of_peak_blocks": round((sr.get_stat("plan_items_lr") * _LR + sr.get_stat("plan_items_2x") * 2 * 9 * 64 * 64 +
+                                             sr.get_stat("plan_items_4x") * 2 * 9 * (2 * 64 * 64 + 64 * 3)) * 512 / dt / 1e12 / PEAK_F16_TFLOPS, 4),
                "checksum": int(d_out[::97, ::89].to(torch.int64).sum().item())}
         # one more, profiled, frame (outside the timed steps): the HBM-bound pre / post kernels against their algorithmic bytes
         # (pre 3 B in + 64 B out per padded px; post 6 B x slots in + 3 B out per output px).  Under TTA the

@@ -371,6 +371,14 @@ int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value)
     if (k == "plan_batches") *value = e.plans.empty() ? 0.0 : double(e.plans.front().batches.size());
     else if (k == "plan_slots_per_batch") *value = e.plans.empty() ? 0.0 : double(e.plans.front().slots_per_batch);
     else if (k == "plans") *value = double(e.plans.size());
+    else if (k == "plan_items_lr" || k == "plan_items_2x" || k == "plan_items_4x")
+    { // work items (16 x 32 blocks; a folded item = one block) of the most recently used plan at one resolution level, all batches
+        const int lvl = k == "plan_items_lr" ? 0 : (k == "plan_items_2x" ? 1 : 2);
+        double n = 0;
+        if (!e.plans.empty())
+            for (const auto& b : e.plans.front().batches) n += double(b.items[lvl].size());
+        *value = e.plans.empty() ? 0.0 : n / double(e.plans.front().nimg); // (a merged plan holds the tables of `nimg` images: per image)
+    }
     else if (k == "ws_clamp_mb") *value = e.ws_clamp_bytes < 0 ? -1.0 : double(e.ws_clamp_bytes) / 1048576.0;
     else if (k == "ws_failures") *value = double(e.ws_failures);
     else if (k == "pool_workers") *value = double(share_pool_stat(0));

@@ -73,7 +73,8 @@ thread_local std::string g_transport = "none";
 // extern "C" boundary with the job already queued -- the job is taken back and run on the CALLING thread.  The pool lives on the heap
 // and is never destroyed: a process exits without joining workers that sleep on a condition variable, and a fork()ed child (whose
 // copy of the pool would name threads that do not exist there, so run() would wait for ever and a destructor would join nothing)
-// gets a fresh, empty pool from a pthread_atfork child handler.
+// gets a fresh, empty pool from a pthread_atfork child handler.  Consequence (include/realsr_hip.h says so): once rsr_process_group
+// has run, the library must stay loaded -- dlclose() would unmap the code its sleeping workers return into.
 struct SharePool
 {
     std::mutex m;
@@ -92,7 +93,8 @@ struct SharePool
             {
                 try
                 {
-                    if (std::getenv("RSR_POOL_NO_THREADS")) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again)); // test hook
+                    static const bool no_threads = std::getenv("RSR_POOL_NO_THREADS") != nullptr; // test hook, read once per process
+                    if (no_threads) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
                     workers.emplace_back([this] {
                         std::unique_lock<std::mutex> lk(m);
                         for (;;)
@@ -108,7 +110,7 @@ struct SharePool
                         }
                     });
                 }
-                catch (const std::system_error&)
+                catch (...) // (std::system_error: thread limit; std::bad_alloc from the vector or the std::function: nothing may cross extern "C")
                 {
                     if (int(q.size()) > idle) // nobody will pick it up soon: take the job back (it is the newest) and run it here
                     {
@@ -248,10 +250,10 @@ int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, cons
             return rc;
         }
     }
-    // First contact with a node of several GPUs: every member's workspace budget (default 64 GiB) is capped HERE by what ITS device can
-    // give right now -- 90 % of the free memory behind a reserve for the image buffers of its lanes (a 4K frame: 4 x 0.5 GB) -- and
-    // said once, so that a device another job already fills shows up at creation and not as a failed allocation inside the first frame
-    // (the engine re-checks at every plan and halves the batch if an allocation still fails: engine.cpp get_plan / enqueue_image).
+    // First contact with a node of several GPUs: a device another job already fills is SAID here, once, at creation -- not found out
+    // as a failed allocation inside the first frame.  The budget itself is left alone (a cap planted here would outlive a
+    // neighbour that held the memory only for a moment): every plan is bounded by what the device can give when it is built, and a
+    // batch whose workspace still cannot be allocated is halved and re-planned (engine.cpp get_plan / enqueue_images).
     for (int i = 0; i < n; i++)
     {
         size_t f = 0, t = 0;
@@ -259,12 +261,10 @@ int rsr_create_group(rsr_ctx** out, const int* gpuids, int n, int tta_mode, cons
         Engine& e = out[i]->e;
         std::lock_guard<std::mutex> lk(e.mu);
         const long long room_mb = (long long)(f / 10 * 9 >> 20) - 2048;
-        const long long before = e.max_workspace_mb;
-        e.max_workspace_mb = std::max<long long>(1024, std::min(before, room_mb));
-        if (e.max_workspace_mb < before || std::getenv("RSR_VERBOSE"))
+        if (room_mb < e.max_workspace_mb || std::getenv("RSR_VERBOSE"))
             std::fprintf(stderr, "realsr-hip: group member %d on device %d: %.1f of %.1f GiB free, workspace budget %.1f GiB%s\n", i, gpuids[i],
                          double(f) / 1073741824.0, double(t) / 1073741824.0, double(e.max_workspace_mb) / 1024.0,
-                         e.max_workspace_mb < before ? " (capped by the device's free memory)" : "");
+                         room_mb < e.max_workspace_mb ? " -- more than the device can give right now: tile batches will be sized by its free memory, plan by plan" : "");
     }
     g_transport = "host";
     bool done = false;

@@ -158,9 +158,12 @@ def check_frame_golden(out, name, img, bin_path, T):
 
 def rotating_tiles(xt, yt, k=6):
     """k tiles of an xt x yt grid for the LIVE oracle: the corner, one of the last column, two of the last row (the three edge-tile
-    shapes) and interior ones; which ones rotates with the calendar day (RSR_ROTATE=<int> pins it), so that successive runs walk
-    over the frame while a single run stays short."""
-    seed = int(os.environ.get("RSR_ROTATE", int(time.time() // 86400)))
+    shapes) and interior ones.  The choice is FIXED (seed 6) so that a failure reproduces on the next run and runs are comparable
+    (ADVICE r05); RSR_ROTATE=<int> picks another subset, RSR_ROTATE=day the calendar day's (a scheduled job that walks over the frame).
+    Every tile is covered by the committed samples in any case (check_frame_golden)."""
+    rot = os.environ.get("RSR_ROTATE", "6")
+    seed = int(time.time() // 86400) if rot == "day" else int(rot)
+    print("live-oracle tile subset: RSR_ROTATE=%d" % seed)
     rng = np.random.default_rng(seed)
     tiles = [(xt - 1, yt - 1)]
     if yt > 1:

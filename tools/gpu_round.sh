@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box session: bench JSON, rocprofv3 kernel-trace stats, PMC passes (HBM traffic + MFMA / LDS / clock counters).
-# Usage: tools/gpu_round.sh <tag>  (default r05)     -> gpurun_out/<tag>/{bench.json,power_clock.txt,kernel_stats.csv,pmc_traffic.txt,pmc_counters.txt}
+# Usage: tools/gpu_round.sh <tag>  (default r06)     -> gpurun_out/<tag>/{bench.json,power_clock.txt,kernel_stats.csv,pmc_traffic.txt,pmc_counters.txt}
 # Copy the summaries you want judged into profiles/ (tracked).
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -31,3 +31,9 @@ rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 $OUT/pmc5
 ls -la $OUT; cat $OUT/pmc_traffic.txt | head -30
 # A/B of the wave layout for the 64-output-channel convs (flow_flags 1) and of the streamed-weight build (4), alternating
 timeout 300 python $R/tools/ab_options.py --config C2 --variants "flow_flags=0;flow_flags=1;flow_flags=4" --rounds 3 > $OUT/ab_flags.log 2>&1; grep -v amdgpu.ids $OUT/ab_flags.log
+# precise mode (rsr_set_option precise 1): alternating A/B on C2 and C3, the per-class cost, and the kernel trace of a precise C2 frame
+( timeout 300 python $R/tools/ab_options.py --config C2 --variants "precise=0;precise=1" --rounds 4; timeout 300 python $R/tools/ab_options.py --config C3 --variants "precise=0;precise=1" --rounds 2 --frames 3; timeout 300 python $R/tools/precise_cost.py 3 ) 2>&1 | grep -v amdgpu.ids > $OUT/precise_cost.txt; cat $OUT/precise_cost.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_p -- python $R/tools/ab_options.py --config C2 --variants "precise=1" --rounds 1 --frames 5 > $OUT/trace_p.log 2>&1; echo "precise trace rc=$?"
+find $OUT/trace_p -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/precise_kernel_stats.csv; rm -rf $OUT/trace_p
+# small images of concurrent calls merged into one tile batch
+timeout 600 python $R/tools/small_image_probe.py 64 2>&1 | grep -v amdgpu.ids > $OUT/small_images.txt; cat $OUT/small_images.txt

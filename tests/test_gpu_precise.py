@@ -7,6 +7,7 @@ halves the pre-quantise error, and these tests hold the engine to it -- layer by
 fp32 oracle with the tolerance SURVEY.md 8(c) set (max <= 2e-3, p99.9 <= 5e-4), end to end +-1 uint8 incl. the wide-swing
 channel-spread stand-in that the fp16-storage default misses by one byte in three million."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -203,3 +204,30 @@ def test_precise_mode_holds_the_bar_on_the_wide_swing_model(tmp_path_factory):
         assert dd.max() <= 1
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c5"])
+def test_precise_baseline_frames_against_golden_samples(name):
+    """The BASELINE frames C2 (1080p, tile 200), C3 (4K, tile 400) and C5 (models-DF2K_JPEG stand-in, 1080p, TTA x8) in PRECISE mode:
+    all 60 tiles of each within +-1 of the committed strided oracle samples (tests/golden/frame_c*.npz, written from the fp32 oracle by
+    tests/golden/make_frames.py -- the same files the default-mode tests of tests/test_gpu_round2.py use), and FEWER samples differ than
+    with fp16 storage (5 - 6 % there).  C2 / C3: conv_last writes the image from its fp32 result (EPI 6); C5: eight planar fp32 blobs per
+    tile merged by postproc_tiles_lds<float>."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_frames
+    import oracle_pool
+    mdir, wseed, iseed, w, h, T, tta = make_frames.FRAMES[name]
+    d = synth.make_model_dir(os.environ.get("RSR_MODELS", "/tmp/rsr_models"), mdir, wseed)
+    pp, bp = os.path.join(d, "x4.param"), os.path.join(d, "x4.bin")
+    img = synth.make_image(iseed, w, h)
+    s = R.RealSR(0, tta_mode=bool(tta))
+    try:
+        s.load(pp, bp)
+        s.tilesize = T
+        s.set_option("precise", 1)
+        out = s.process(img)
+    finally:
+        s.close()
+    n, frac = oracle_pool.check_frame_golden(out, name, img, bp, T)
+    print("%s, precise mode: %d of 60 tiles within +-1 of the golden oracle samples, %.2f %% of the samples differ" % (name.upper(), n, 100 * frac))
+    assert n == 60 and frac < 0.035

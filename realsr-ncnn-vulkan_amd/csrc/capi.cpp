@@ -398,6 +398,7 @@ int rsr_get_stat(rsr_ctx* ctx, const char* key, double* value)
     else if (k == "merged_batches") *value = double(e.merged_batches.load());
     else if (k == "merged_images") *value = double(e.merged_images.load());
     else if (k == "merged_widest") *value = double(e.merged_widest.load());
+    else if (k == "merged_mixed") *value = double(e.merged_mixed.load());
     else return e.fail(RSR_E_ARG, "unknown stat " + k);
     return RSR_OK;
 }
@@ -425,6 +426,8 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value)
         if (value < 1 || value > kMaxMerge) return ctx->e.fail(RSR_E_ARG, "merge out of range (1 .. 16)");
         ctx->e.merge_max = int(value);
     }
+    else if (k == "merge_mixed")
+        ctx->e.merge_mixed = value != 0;
     else if (k == "merge_target_items")
     {
         if (value < 1 || value > (1 << 20)) return ctx->e.fail(RSR_E_ARG, "merge_target_items out of range");

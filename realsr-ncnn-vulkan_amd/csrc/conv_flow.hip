@@ -618,7 +618,9 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
         if (a.out_u8)
         {
             const int ox = it.pad0 + x, ow = pad2_w(it.pad2), oh = pad2_h(it.pad2);
-            uint8_t* const oimg = a.out_u8s[pad2_img(it.pad2)]; // (a merged batch: the tile's own image)
+            const int oim = pad2_img(it.pad2); // (a merged batch: the tile's own image and its row pitch)
+            uint8_t* const oimg = a.out_u8s[oim];
+            const int opitch = a.out_u8_ws[oim];
 #pragma unroll
             for (int rr = 0; rr < 4; rr++)
             {
@@ -627,7 +629,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 const int rx = x - a.out_u8_crop, ry = y - a.out_u8_crop;
                 if (rx >= 0 && rx < ow && ry >= 0 && ry < oh)
                 {
-                    uint8_t* o = oimg + ((long long)(it.pad1 + y) * a.out_u8_w + ox) * 3;
+                    uint8_t* o = oimg + ((long long)(it.pad1 + y) * opitch + ox) * 3;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                     {

@@ -98,6 +98,11 @@ Engine::~Engine()
     for (hipEvent_t e : sync_events) (void)hipEventDestroy(e);
     if (merge_mid) (void)hipEventDestroy(merge_mid);
     if (merge_done) (void)hipEventDestroy(merge_done);
+    for (int k = 0; k < 3; k++)
+    {
+        if (mix_ev[k]) (void)hipEventDestroy(mix_ev[k]);
+        if (mix_tab[k].p) (void)hipFree(mix_tab[k].p);
+    }
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -416,6 +421,39 @@ long long Engine::device_avail(int w, int h, int c)
     return std::max<long long>(0, ((long long)f + held) / 10 * 9 - lanes_need);
 }
 
+// The padded tiles [tile0, tile1) of a w x h image (tile grid: realsr.cpp:170-171; tile geometry: realsr.cpp:178-181,237,246-249),
+// appended to `all` as tiles of image `img` of a batch; cap / mtw / mth: running maxima of tile pixels / width / height.
+static void image_tiles(int w, int h, int T, int P, int scale, int tile0, int tile1, int img, std::vector<BaseTile>& all, long long& cap, int& mtw, int& mth)
+{
+    const int xtiles = (w + T - 1) / T;
+    for (int ti = tile0; ti < tile1; ti++)
+    {
+        const int yi = ti / xtiles, xi = ti - yi * xtiles;
+        const int twn = std::min((xi + 1) * T, w) - xi * T;
+        const int thn = std::min((yi + 1) * T, h) - yi * T;
+        BaseTile t;
+        // Padded tile pixel (gx,gy) samples image pixel reflect101(gx + x_org), reflect101(gy + y_org).
+        // The reference reflects against the uploaded row BAND (realsr_preproc.comp:56-62 with
+        // crop_y = min(yi*T, P), realsr.cpp:404); the band starts at max(yi*T-P,0) and ends at
+        // min((yi+1)*T+P, h), so reflection only ever triggers where the band edge IS the image edge:
+        // reflecting against the image gives the same pixel, and the whole image can stay resident.
+        t.x_org = xi * T - P;
+        t.y_org = yi * T - P;
+        t.tw = twn + 2 * P;
+        t.th = thn + 2 * P;
+        t.slot0 = 0;
+        t.out_x = xi * T * scale;
+        t.out_y = yi * T * scale;
+        t.out_w = twn * scale;
+        t.out_h = thn * scale;
+        t.img = img;
+        all.push_back(t);
+        cap = std::max(cap, (long long)t.tw * t.th);
+        mtw = std::max(mtw, t.tw);
+        mth = std::max(mth, t.th);
+    }
+}
+
 int Engine::get_plan(int w, int h, int c, int tile0, int tile1, int nimg, Plan*& out)
 {
     const long long kBytesPerPx = bytes_per_px();
@@ -436,33 +474,10 @@ int Engine::get_plan(int w, int h, int c, int tile0, int tile1, int nimg, Plan*&
     int mtw = 0, mth = 0;
     if (tile0 < 0 || tile1 > xtiles * ytiles || tile0 >= tile1) return fail(RSR_E_ARG, "tile range outside the image");
     if (nimg < 1 || nimg > kMaxMerge || (nimg > 1 && (tile0 != 0 || tile1 != xtiles * ytiles))) return fail(RSR_E_ARG, "merged batches take whole images");
-    for (int im = 0; im < nimg; im++)
-    for (int ti = tile0; ti < tile1; ti++)
-        {
-            const int yi = ti / xtiles, xi = ti - yi * xtiles;
-            const int twn = std::min((xi + 1) * T, w) - xi * T;
-            const int thn = std::min((yi + 1) * T, h) - yi * T;
-            BaseTile t;
-            // Padded tile pixel (gx,gy) samples image pixel reflect101(gx + x_org), reflect101(gy + y_org).
-            // The reference reflects against the uploaded row BAND (realsr_preproc.comp:56-62 with
-            // crop_y = min(yi*T, P), realsr.cpp:404); the band starts at max(yi*T-P,0) and ends at
-            // min((yi+1)*T+P, h), so reflection only ever triggers where the band edge IS the image edge:
-            // reflecting against the image gives the same pixel, and the whole image can stay resident.
-            t.x_org = xi * T - P;
-            t.y_org = yi * T - P;
-            t.tw = twn + 2 * P;
-            t.th = thn + 2 * P;
-            t.slot0 = 0;
-            t.out_x = xi * T * scale;
-            t.out_y = yi * T * scale;
-            t.out_w = twn * scale;
-            t.out_h = thn * scale;
-            t.img = im;
-            all.push_back(t);
-            cap = std::max(cap, (long long)t.tw * t.th);
-            mtw = std::max(mtw, t.tw);
-            mth = std::max(mth, t.th);
-        }
+    for (int im = 0; im < nimg; im++) image_tiles(w, h, T, P, scale, tile0, tile1, im, all, cap, mtw, mth);
+    // every merged batch -- of one geometry (this plan) or of several (enqueue_mixed) -- gives its slots the capacity of a full tile: the
+    // workspace layout, hence its guards, then stays put from batch to batch whatever small images come
+    if (nimg > 1) cap = std::max(cap, (long long)(T + 2 * P) * (T + 2 * P));
     // The kernels address a plane through 32-bit byte offsets (raw buffer resources, out-of-range sentinel 2^31): the
     // largest plane is the 4x level, 16 * cap pixels * 32 B, and an MFMA wave reaches the 2 planes of its n-tile (4 with two n-tiles
     // per wave, flow_flags bit 0) from one base; the stores' range limit is "end of the plane + the plane's offset" (conv_flow.hip
@@ -705,7 +720,7 @@ int Engine::launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st)
     return RSR_OK;
 }
 
-int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs, int nimg, int fused_out_w, int split_slot, hipEvent_t ev_half,
+int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs, int nimg, const int* fused_out_ws, int split_slot, hipEvent_t ev_half,
                         hipEvent_t ev_mid, int mid_rdb, int nslots_used)
 {
     const int nslots = (nslots_used > 0 && nslots_used < b.nslots) ? nslots_used : b.nslots;
@@ -863,8 +878,12 @@ int Engine::run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fu
             if (fused_outs)
             { // non-TTA RGB with conv3x3_flow: conv_last applies realsr_postproc.comp itself and writes the image(s)
                 a.out_u8 = fused_outs[0];
-                for (int i = 0; i < nimg && i < kMaxMerge; i++) a.out_u8s[i] = fused_outs[i];
-                a.out_u8_w = fused_out_w;
+                for (int i = 0; i < nimg && i < kMaxMerge; i++)
+                {
+                    a.out_u8s[i] = fused_outs[i];
+                    a.out_u8_ws[i] = fused_out_ws[i];
+                }
+                a.out_u8_w = fused_out_ws[0];
                 a.out_u8_crop = prepadding * scale;
                 a.out_u8_bgr = bgr ? 1 : 0;
             }
@@ -959,34 +978,18 @@ int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg
     if (rc == RSR_OK && unclamp_attempt) { clamp_backoff = 4; clamp_fail_avail = -1; } // the full size fits again: forget the history
     if (rc != RSR_OK) return rc;
     const Plan& plan = *planp;
-    constexpr int pc = plane_ch();
     mark_begin(st);
     int done = 0, total = 0;
     for (const Plan::Batch& b : plan.batches) total += b.ntiles;
     const int tiles_wanted = (tile1 - tile0) * nimg; // the tiles of the first nimg images (all of the plan's unless the batch is narrower)
+    int ws[kMaxMerge], hs[kMaxMerge];
+    for (int i = 0; i < nimg; i++) { ws[i] = w; hs[i] = h; }
     for (const Plan::Batch& b : plan.batches)
     {
         const int ntiles = std::min(b.ntiles, tiles_wanted - b.tile0); // of this batch
         if (ntiles <= 0) break;
-        const int nslots_used = ntiles * (tta ? 8 : 1);
-        PreArgs pa;
-        std::memset(&pa, 0, sizeof pa);
-        for (int i = 0; i < nimg; i++) pa.imgs[i] = static_cast<const uint8_t*>(d_in[i]);
-        pa.nimgs = nimg;
-        pa.w = w; pa.h = h; pa.c = c;
-        pa.tiles = b.d_tiles;
-        pa.ntiles = ntiles;
-        pa.tta = tta;
-        pa.in_plane = static_cast<char*>(b_in.p) + kGuard;
-        pa.slot_stride = (32 / pc) * (plan.cap_px * pc * 2 + kGuard);
-        pa.bgr = bgr ? 1 : 0;
-        pa.plane_ch = pc;
-        pa.variant = (dbg & 32768) ? 1 : ((dbg & 65536) ? 2 : 0);
-        launch_preproc_tiles(pa, plan.max_tw, plan.max_th, st);
-        mark(0, 0, b.px[0] / (tta ? 8 : 1) * c + b.px[0] * 64, st);
-        // conv_last writes the uint8 image directly when no TTA merge / alpha channel needs the fp16 blob (dbg 8192: off)
-        const bool fused = !tta && c == 3 && !(dbg & 8192);
         // host calls: split the 4x tail at a tile-row boundary so that the first output rows can travel while the rest is computed
+        const bool fused = !tta && c == 3 && !(dbg & 8192);
         int split_slot = 0;
         if (fused && nimg == 1 && ev_half && half_rows && plan.batches.size() == 1 && !profiling && !(dbg & 16384))
         {
@@ -997,37 +1000,13 @@ int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg
                 *half_rows = size_t(b.tiles[size_t(split_slot)].out_y - b.tiles[0].out_y); // output rows finished at ev_half
             }
         }
-        uint8_t* outs[kMaxMerge];
-        for (int i = 0; i < nimg; i++) outs[i] = static_cast<uint8_t*>(d_out[i]);
-        // the throttle event of a merged batch (Engine::submit_merged): behind the RDB that leaves about half an image's worth of network
-        // ahead -- the time the next batch's launches take to enqueue
         const bool last_batch = b.tile0 + b.ntiles >= tiles_wanted;
-        rc = run_network(b, st, fused ? outs : nullptr, nimg, w * scale, split_slot, ev_half, last_batch ? ev_mid : nullptr,
-                         kNumRDB - 1 - std::max(2, kNumRDB / (2 * std::max(1, nimg))), nslots_used);
+        rc = launch_batch(b, plan.cap_px, plan.max_tw, plan.max_th, plan.out_row0, d_in, d_out, ws, hs, nimg, c, ntiles, st, split_slot, ev_half,
+                          last_batch ? ev_mid : nullptr);
         if (rc != RSR_OK) return rc;
         if (progress && !merged) // one call per TILE, like the reference's line per tile (realsr.cpp:481), issued when the tile's batch is enqueued
             for (int i = 1; i <= b.ntiles; i++) progress(done + i, total, progress_user); // (a merged batch: every caller reports its own image)
         done += b.ntiles;
-        if (fused) continue;
-        PostArgs po;
-        std::memset(&po, 0, sizeof po);
-        po.planar3 = b_out3.p;
-        po.f32 = precise ? 1 : 0;
-        po.slot_stride = plan.cap_px * (precise ? 192 : 96);
-        po.tiles = b.d_tiles;
-        po.ntiles = ntiles;
-        po.tta = tta;
-        po.crop = prepadding * scale;
-        for (int i = 0; i < nimg; i++) { po.outs[i] = outs[i]; po.in_imgs[i] = static_cast<const uint8_t*>(d_in[i]); }
-        po.nimgs = nimg;
-        po.out_w = w * scale; po.out_h = h * scale; po.c = c;
-        po.out_row0 = plan.out_row0;
-        po.in_w = w; po.in_h = h;
-        po.tilesize = tilesize;
-        po.bgr = bgr ? 1 : 0;
-        po.variant = (dbg & 32768) ? 1 : ((dbg & 65536) ? 2 : 0);
-        launch_postproc_tiles(po, (plan.max_tw - 2 * prepadding) * scale, (plan.max_th - 2 * prepadding) * scale, st);
-        mark(2, 0, b.px[2] / (tta ? 8 : 1) * (6.0 * (tta ? 8 : 1) + c), st);
     }
     HIP_TRY(hipGetLastError());
     if (profiling)
@@ -1036,6 +1015,134 @@ int Engine::enqueue_images(const void* const* d_in, void* const* d_out, int nimg
         prof.calls++;
         for (const Plan::Batch& b : plan.batches) prof.tiles += b.nslots;
     }
+    return RSR_OK;
+}
+
+// preproc -> network -> postproc of the first `ntiles` tiles of one tile batch on `st` (mu held; the workspace is laid out for cap_px).
+// The images of the batch may differ in size (ws / hs): every tile carries the index of its image.
+int Engine::launch_batch(const Plan::Batch& b, long long cap_px, int max_tw, int max_th, int out_row0, const void* const* d_in, void* const* d_out,
+                         const int* ws, const int* hs, int nimg, int c, int ntiles, hipStream_t st, int split_slot, hipEvent_t ev_half, hipEvent_t ev_mid)
+{
+    constexpr int pc = plane_ch();
+    const int per = tta ? 8 : 1, nslots_used = ntiles * per;
+    PreArgs pa;
+    std::memset(&pa, 0, sizeof pa);
+    for (int i = 0; i < nimg; i++)
+    {
+        pa.imgs[i] = static_cast<const uint8_t*>(d_in[i]);
+        pa.ws[i] = ws[i];
+        pa.hs[i] = hs[i];
+    }
+    pa.nimgs = nimg;
+    pa.c = c;
+    pa.tiles = b.d_tiles;
+    pa.ntiles = ntiles;
+    pa.tta = tta;
+    pa.in_plane = static_cast<char*>(b_in.p) + kGuard;
+    pa.slot_stride = (32 / pc) * (cap_px * pc * 2 + kGuard);
+    pa.bgr = bgr ? 1 : 0;
+    pa.plane_ch = pc;
+    pa.variant = (dbg & 32768) ? 1 : ((dbg & 65536) ? 2 : 0);
+    launch_preproc_tiles(pa, max_tw, max_th, st);
+    mark(0, 0, b.px[0] / per * c + b.px[0] * 64, st);
+    // conv_last writes the uint8 image directly when no TTA merge / alpha channel needs the fp16 blob (dbg 8192: off)
+    const bool fused = !tta && c == 3 && !(dbg & 8192);
+    uint8_t* outs[kMaxMerge];
+    int out_ws[kMaxMerge];
+    for (int i = 0; i < nimg; i++)
+    {
+        outs[i] = static_cast<uint8_t*>(d_out[i]);
+        out_ws[i] = ws[i] * scale;
+    }
+    // the throttle event of a merged batch (Engine::submit_merged): behind the RDB that leaves about half an image's worth of network
+    // ahead -- the time the next batch's launches take to enqueue
+    int rc = run_network(b, st, fused ? outs : nullptr, nimg, out_ws, split_slot, ev_half, ev_mid, kNumRDB - 1 - std::max(2, kNumRDB / (2 * std::max(1, nimg))),
+                         nslots_used);
+    if (rc != RSR_OK || fused) return rc;
+    PostArgs po;
+    std::memset(&po, 0, sizeof po);
+    po.planar3 = b_out3.p;
+    po.f32 = precise ? 1 : 0;
+    po.slot_stride = cap_px * (precise ? 192 : 96);
+    po.tiles = b.d_tiles;
+    po.ntiles = ntiles;
+    po.tta = tta;
+    po.crop = prepadding * scale;
+    for (int i = 0; i < nimg; i++)
+    {
+        po.outs[i] = outs[i];
+        po.out_ws[i] = out_ws[i];
+        po.in_imgs[i] = static_cast<const uint8_t*>(d_in[i]);
+        po.in_ws[i] = ws[i];
+    }
+    po.nimgs = nimg;
+    po.c = c;
+    po.out_row0 = out_row0;
+    po.tilesize = tilesize;
+    po.bgr = bgr ? 1 : 0;
+    po.variant = (dbg & 32768) ? 1 : ((dbg & 65536) ? 2 : 0);
+    launch_postproc_tiles(po, (max_tw - 2 * prepadding) * scale, (max_th - 2 * prepadding) * scale, st);
+    mark(2, 0, b.px[2] / per * (6.0 * per + c), st);
+    return RSR_OK;
+}
+
+// A merged batch of images that DIFFER in size (a directory of thumbnails, sprites, crops ...): no cached plan can serve it -- the
+// tile and work-item tables are built here, for exactly these images, and uploaded into one of three rotating device buffers (the
+// throttle of submit_merged leaves at most the previous batch in flight when the next one is formed; the buffer's event makes sure).
+// All slots get the capacity of a full tile, (T + 2P)^2, whatever the images: the workspace layout (hence its guards) then does not
+// change from batch to batch.  mu held.
+int Engine::enqueue_mixed(MergeReq* const* g, int n, hipStream_t st, hipEvent_t ev_mid)
+{
+    const int T = tilesize, P = prepadding, per = tta ? 8 : 1, c = g[0]->c;
+    Plan::Batch b;
+    long long cap = 0;
+    int mtw = 0, mth = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const int xt = (g[i]->w + T - 1) / T, yt = (g[i]->h + T - 1) / T;
+        image_tiles(g[i]->w, g[i]->h, T, P, scale, 0, xt * yt, i, b.tiles, cap, mtw, mth);
+    }
+    cap = (long long)(T + 2 * P) * (T + 2 * P);
+    b.tile0 = 0;
+    b.ntiles = int(b.tiles.size());
+    b.nslots = b.ntiles * per;
+    for (int i = 0; i < b.ntiles; i++)
+    {
+        BaseTile& t = b.tiles[size_t(i)];
+        t.slot0 = i * per;
+        for (int k = 0; k < per; k++) b.dims.push_back(k < 4 ? TileDim{t.th, t.tw} : TileDim{t.tw, t.th}); // realsr.cpp:251-258
+    }
+    if (cap * 16 * 32 * ((flow_flags & 1) ? 4 : 2) + 4 * kGuard >= (1ll << 31)) return fail(RSR_E_ARG, "tilesize too large");
+    const long long need = (long long)b.nslots * cap * bytes_per_px();
+    const long long avail = device_avail(g[0]->w, g[0]->h, c);
+    if (need > max_workspace_mb * 1024 * 1024 || (avail >= 0 && need > avail)) return fail(RSR_E_NOMEM, "merged batch exceeds the workspace budget");
+    b.trim4 = trim_tail ? P * scale : 0;
+    make_items(b, fold_cols, tta ? -1 : P * scale, b.trim4, 0);
+    HIP_TRY(hipSetDevice(device));
+    const int k = int(mix_seq++ % 3);
+    if (mix_ev[k]) HIP_TRY(hipEventSynchronize(mix_ev[k])); // the batch that read this buffer last has finished
+    int rc;
+    if ((rc = ensure(mix_tab[k], batch_table_bytes(b))) != RSR_OK) return rc;
+    char* d = static_cast<char*>(mix_tab[k].p);
+    const hipError_t e = upload_batch(b, d, false);
+    if (e != hipSuccess) return fail(RSR_E_DEVICE, std::string("merged batch table upload: ") + hipGetErrorString(e));
+    if ((rc = ensure_workspace(b.nslots, cap, st)) != RSR_OK) return rc;
+    const void* ins[kMaxMerge];
+    void* outs[kMaxMerge];
+    int ws[kMaxMerge], hs[kMaxMerge];
+    for (int i = 0; i < n; i++)
+    {
+        ins[i] = g[i]->d_in;
+        outs[i] = g[i]->d_out;
+        ws[i] = g[i]->w;
+        hs[i] = g[i]->h;
+    }
+    rc = launch_batch(b, cap, mtw, mth, 0, ins, outs, ws, hs, n, c, b.ntiles, st, 0, nullptr, ev_mid);
+    if (rc != RSR_OK) return rc;
+    if (!mix_ev[k] && hipEventCreateWithFlags(&mix_ev[k], hipEventDisableTiming) != hipSuccess) mix_ev[k] = nullptr;
+    if (mix_ev[k]) HIP_TRY(hipEventRecord(mix_ev[k], st));
+    else HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
     return RSR_OK;
 }
 
@@ -1056,6 +1163,7 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
         {
             MergeReq r;
             r.d_in = d_in; r.d_out = d_out; r.w = w; r.h = h; r.c = c; r.T = T;
+            r.items = image_items(w, h, merge_target_items);
             const int rc = submit_merged(r);
             if (rc != RSR_OK) return rc;
             const hipError_t e = hipEventSynchronize(r.ev_done);
@@ -1129,21 +1237,27 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
 // batch aims at: a few launches' worth of blocks per CU by itself) or merging is off; else as many as keep the batch at
 // `merge_target_items` LR-level work items (16 x 32 blocks; x8 under TTA), at most merge_max.  ONE plan of that width serves every
 // narrower batch (enqueue_images: plan_nimg).
-int Engine::merge_width(int w, int h, int c) const
+// LR-level work items (16 x 32 blocks; x8 under TTA) of a w x h image at the current tile size; stops counting beyond `limit`
+long long Engine::image_items(int w, int h, long long limit) const
 {
-    (void)c;
-    if (merge_max <= 1 || profiling) return 1;
     const int T = tilesize, P = prepadding;
-    if (T < 1) return 1;
+    if (T < 1) return limit + 1;
     long long items = 0;
     for (int y0 = 0; y0 < h; y0 += T)
         for (int x0 = 0; x0 < w; x0 += T)
         {
             const long long th = std::min(y0 + T, h) - y0 + 2 * P, tw = std::min(x0 + T, w) - x0 + 2 * P;
-            items += ((th + kBlkH - 1) / kBlkH) * ((tw + kBlkW - 1) / kBlkW);
-            if (items * 4 > merge_target_items) return 1;
+            items += ((th + kBlkH - 1) / kBlkH) * ((tw + kBlkW - 1) / kBlkW) * (tta ? 8 : 1);
+            if (items > limit) return items;
         }
-    items *= tta ? 8 : 1;
+    return items;
+}
+
+int Engine::merge_width(int w, int h, int c) const
+{
+    (void)c;
+    if (merge_max <= 1 || profiling) return 1;
+    const long long items = image_items(w, h, merge_target_items / 4);
     if (items * 4 > merge_target_items) return 1;
     return int(std::max<long long>(1, std::min<long long>(std::min(merge_max, kMaxMerge), merge_target_items / std::max<long long>(items, 1))));
 }
@@ -1166,7 +1280,16 @@ int Engine::run_group(MergeReq* const* g, int n)
     }
     if (!merge_mid && hipEventCreateWithFlags(&merge_mid, hipEventDisableTiming) != hipSuccess) merge_mid = nullptr;
     merge_mid_used = false;
-    int rc = enqueue_images(ins, outs, n, g[0]->w, g[0]->h, g[0]->c, stream, 0, -1, nullptr, nullptr, merge_mid, merge_width(g[0]->w, g[0]->h, g[0]->c));
+    bool same = true;
+    for (int i = 1; i < n; i++) same = same && g[i]->w == g[0]->w && g[i]->h == g[0]->h;
+    int rc;
+    if (same) // one geometry: the cached plan of merge_width images, launched in a prefix
+        rc = enqueue_images(ins, outs, n, g[0]->w, g[0]->h, g[0]->c, stream, 0, -1, nullptr, nullptr, merge_mid, merge_width(g[0]->w, g[0]->h, g[0]->c));
+    else
+    {
+        rc = enqueue_mixed(g, n, stream, merge_mid);
+        if (rc == RSR_OK) merged_mixed++;
+    }
     if (rc == RSR_OK)
         for (int i = 0; i < n && rc == RSR_OK; i++)
         {
@@ -1234,12 +1357,23 @@ int Engine::submit_merged(MergeReq& r)
         // they arrive within microseconds -- 16 callers that start together would otherwise open with batches of 1, 1, 7, 7.
         for (int spins = 0; merge_inbound.load() > 0 && int(cq.size()) < kMaxMerge && spins < 8; spins++)
             cq_cv.wait_for(lk, std::chrono::microseconds(50));
+        // The batch: the head of the queue and, in order of arrival, the calls behind it that fit -- same channel count and tile size (one
+        // preproc / conv_last / postproc launch serves all), images of ANY small size (option merge_mixed 0: of the head's size only) --
+        // while the batch stays within merge_target_items work items and merge_max images.
         MergeReq* g[kMaxMerge];
         int n = 0;
         const MergeReq* head = cq.front();
-        const int width = merge_width(head->w, head->h, head->c);
+        const int width = merge_mixed ? std::min(merge_max, kMaxMerge) : merge_width(head->w, head->h, head->c);
+        long long items = 0;
         for (MergeReq* q : cq)
-            if (n < width && q->w == head->w && q->h == head->h && q->c == head->c && q->T == head->T) g[n++] = q;
+        {
+            if (n >= width) break;
+            if (q->c != head->c || q->T != head->T) continue;
+            if (!merge_mixed && (q->w != head->w || q->h != head->h)) continue;
+            if (n > 0 && items + q->items > merge_target_items) continue;
+            g[n++] = q;
+            items += q->items;
+        }
         // Every width up to merge_width shares one plan (enqueue_images: plan_nimg), so any number can be taken.  All of them when the GPU
         // has run dry.  While the previous batch is still running, though, taking everything that waits makes the batch sizes
         // ALTERNATE for ever (the callers of batch n - 1 are exactly what waits when batch n + 1 is formed: 1, 15, 1, 15 ... is as stable
@@ -1422,6 +1556,7 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     {
         MergeReq r;
         r.d_in = L->d_in.p; r.d_out = dbase; r.w = w; r.h = h; r.c = c; r.T = T;
+        r.items = image_items(w, h, merge_target_items);
         r.ev_in = L->ev_in;
         r.ev_done = L->ev_done;
         inbound.release(); // (it is in the queue the moment submit_merged has the lock: the leader's wait ends either way)

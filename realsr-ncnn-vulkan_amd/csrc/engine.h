@@ -105,6 +105,7 @@ struct MergeReq
     const void* d_in = nullptr;
     void* d_out = nullptr;
     int w = 0, h = 0, c = 0, T = 0;
+    long long items = 0;          // LR-level work items of the image (Engine::image_items)
     hipEvent_t ev_in = nullptr;   // the input is complete behind this event (null: it already is)
     hipEvent_t ev_done = nullptr; // recorded on the compute stream behind the batch (null: the leader takes one from the pool -> ev_done_pool)
     bool pool_event = false;      // ev_done came from Engine::take_event: the caller gives it back
@@ -198,6 +199,12 @@ struct Engine
     std::atomic<long long> merged_batches{0}, merged_images{0}, merged_widest{0}; // stats
     std::atomic<int> merge_inbound{0}; // calls with a small image that are on their way to submit_merged (uploading): a leader waits a moment for them
     long long device_direct = 0; // rsr_process_device calls that ran on the caller's own stream (the engine was idle), under mu
+    bool merge_mixed = true;         // option "merge_mixed": a merged batch may hold images of different sizes (0: of one geometry only)
+    DevBuf mix_tab[3];               // rotating device tables of such batches
+    hipEvent_t mix_ev[3] = {nullptr, nullptr, nullptr};
+    unsigned long long mix_seq = 0;
+    std::atomic<long long> merged_mixed{0}; // stat: merged batches whose images differed in size
+    long long image_items(int w, int h, long long limit) const;
     int merge_width(int w, int h, int c) const; // images of this geometry one batch may take (1: not a small image / merging off)
     int submit_merged(MergeReq& r);             // returns when r's batch has been ENQUEUED (r.ev_done recorded) or failed
     int run_group(MergeReq* const* g, int n);   // mu inside
@@ -251,8 +258,11 @@ struct Engine
     // fused_outs: non-null = conv_last writes the uint8 images itself (one pointer per image of the batch)
     // ev_mid: recorded behind the middle RDB (a merged batch's throttle event)
     // mid_rdb >= 0: ev_mid is recorded behind that RDB.  nslots_used < b.nslots: only the first slots of the batch (a merged batch narrower than its plan)
-    int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs = nullptr, int nimg = 1, int fused_out_w = 0, int split_slot = 0,
+    int run_network(const Plan::Batch& b, hipStream_t st, uint8_t* const* fused_outs = nullptr, int nimg = 1, const int* fused_out_ws = nullptr, int split_slot = 0,
                     hipEvent_t ev_half = nullptr, hipEvent_t ev_mid = nullptr, int mid_rdb = -1, int nslots_used = -1);
+    int launch_batch(const Plan::Batch& b, long long cap_px, int max_tw, int max_th, int out_row0, const void* const* d_in, void* const* d_out, const int* ws,
+                     const int* hs, int nimg, int c, int ntiles, hipStream_t st, int split_slot, hipEvent_t ev_half, hipEvent_t ev_mid);
+    int enqueue_mixed(MergeReq* const* g, int n, hipStream_t st, hipEvent_t ev_mid); // a merged batch of images of different sizes: tables built on the fly
     int launch(ConvArgs& a, int ci, const Plan::Batch& b, hipStream_t st);
     int enqueue_image(const void* d_in, int w, int h, int c, void* d_out, hipStream_t st, int tile0 = 0, int tile1 = -1,
                       hipEvent_t ev_half = nullptr, size_t* half_rows = nullptr);

@@ -111,8 +111,10 @@ struct ConvArgs
     long long lo1_off;    // lo planes of res1 = res1 + lo1_off bytes
     long long lo2_off;    // lo planes of res2
     long long out_lo_off; // lo planes of the output = out16 + out_lo_off (0: not kept)
-    // fused conv_last: the uint8 image of every image of a (merged) batch; out_u8 == out_u8s[0] doubles as the mode flag
+    // fused conv_last: the uint8 image of every image of a (merged) batch and its row pitch in pixels (the images of a merged batch may
+    // differ in size); out_u8 == out_u8s[0] doubles as the mode flag
     uint8_t* out_u8s[kMaxMerge];
+    int out_u8_ws[kMaxMerge];
 };
 
 // conv_flow.hip: half-stage ring on 16-channel planes.  flags: 1 = two n-tiles per MFMA wave for 64-cout convs, 2 = no deferred epilogue,
@@ -136,9 +138,10 @@ struct BaseTile
 
 struct PreArgs
 {
-    const uint8_t* imgs[kMaxMerge]; // HWC u8, one per image of the batch (all w x h x c); BaseTile::img selects
+    const uint8_t* imgs[kMaxMerge]; // HWC u8, one per image of the batch (ws[i] x hs[i] x c); BaseTile::img selects
+    int ws[kMaxMerge], hs[kMaxMerge];
     int nimgs;
-    int w, h, c;
+    int c;
     const BaseTile* tiles;
     int ntiles;
     int tta;
@@ -160,11 +163,12 @@ struct PostArgs
     int tta;
     int crop;   // prepadding*scale
     uint8_t* outs[kMaxMerge]; // HWC u8 (4w x 4h x c), one per image of the batch
+    int out_ws[kMaxMerge];    // their row pitches in pixels (4w)
+    int in_ws[kMaxMerge];     // ... and those of the source images (w)
     int nimgs;
-    int out_w, out_h, c;
+    int c;
     int out_row0; // the outs point at output row out_row0 of the x4 image (a tile range's device buffer holds only its rows)
     const uint8_t* in_imgs[kMaxMerge]; // for alpha (c==4): the source images (w x h x 4)
-    int in_w, in_h;
     int tilesize;
     int bgr;
     int variant; // 0 default (LDS-staged under TTA, else one thread per pixel), 1 per-pixel (engine dbg 32768), 2 LDS-staged (dbg 65536)

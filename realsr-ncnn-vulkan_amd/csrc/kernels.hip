@@ -43,9 +43,10 @@ __global__ __launch_bounds__(256) void preproc_tiles(const PreArgs a)
     const int gx = blockIdx.x * 32 + (threadIdx.x & 31);
     const int gy = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (gx >= t.tw || gy >= t.th) return;
-    const int x = reflect101(gx + t.x_org, a.w);
-    const int y = reflect101(gy + t.y_org, a.h);
-    const uint8_t* p = a.imgs[__builtin_amdgcn_readfirstlane(t.img)] + ((long long)y * a.w + x) * a.c;
+    const int im = __builtin_amdgcn_readfirstlane(t.img), iw = a.ws[im], ih = a.hs[im];
+    const int x = reflect101(gx + t.x_org, iw);
+    const int y = reflect101(gy + t.y_org, ih);
+    const uint8_t* p = a.imgs[im] + ((long long)y * iw + x) * a.c;
     const float norm_val = 1 / 255.f;
     const int i0 = a.bgr ? 2 : 0, i2 = a.bgr ? 0 : 2;
     half8 v0;
@@ -96,11 +97,12 @@ __global__ __launch_bounds__(256) void preproc_tiles_lds(const PreArgs a)
     const BaseTile t = a.tiles[blockIdx.z];
     const int gx0 = blockIdx.x * 32, gy0 = blockIdx.y * 32;
     if (gx0 >= t.tw || gy0 >= t.th) return;
-    const uint8_t* const img = a.imgs[__builtin_amdgcn_readfirstlane(t.img)];
+    const int im = __builtin_amdgcn_readfirstlane(t.img), iw = a.ws[im], ih = a.hs[im];
+    const uint8_t* const img = a.imgs[im];
     const int nx = min(32, t.tw - gx0), ny = min(32, t.th - gy0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // source column span [lo, hi] of the block's columns (every wave computes it for itself)
-    int xs = reflect101(gx0 + min(lane & 31, nx - 1) + t.x_org, a.w);
+    int xs = reflect101(gx0 + min(lane & 31, nx - 1) + t.x_org, iw);
     int lo = xs, hi = xs;
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1)
@@ -108,11 +110,11 @@ __global__ __launch_bounds__(256) void preproc_tiles_lds(const PreArgs a)
         lo = min(lo, __shfl_xor(lo, d));
         hi = max(hi, __shfl_xor(hi, d));
     }
-    const long long total = (long long)a.w * a.h * a.c;
+    const long long total = (long long)iw * ih * a.c;
     for (int r = wave; r < ny; r += 4)
     {
-        const int y = reflect101(gy0 + r + t.y_org, a.h);
-        const long long b0 = ((long long)y * a.w + lo) * a.c, b1 = ((long long)y * a.w + hi + 1) * a.c;
+        const int y = reflect101(gy0 + r + t.y_org, ih);
+        const long long b0 = ((long long)y * iw + lo) * a.c, b1 = ((long long)y * iw + hi + 1) * a.c;
         const long long a0 = b0 & ~3ll;
         const int nd = int((b1 - a0 + 3) >> 2); // <= 33 dwords
         if (lane < nd)
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(256) void preproc_tiles_lds(const PreArgs a)
         const int r = (tid >> 5) + 8 * m, cx = tid & 31;
         if (r < ny && cx < nx)
         {
-            const int x = reflect101(gx0 + cx + t.x_org, a.w);
-            const int y = reflect101(gy0 + r + t.y_org, a.h);
-            const int shift = int((((long long)y * a.w + lo) * a.c) & 3);
+            const int x = reflect101(gx0 + cx + t.x_org, iw);
+            const int y = reflect101(gy0 + r + t.y_org, ih);
+            const int shift = int((((long long)y * iw + lo) * a.c) & 3);
             const unsigned char* p = &raw[r][shift + (x - lo) * a.c];
             const _Float16 hr = (_Float16)((float)p[i0] * norm_val), hg = (_Float16)((float)p[1] * norm_val), hb = (_Float16)((float)p[i2] * norm_val);
             uint2 v;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
     const int w = t.tw * 4, h = t.th * 4;
     const long long cstep = (long long)w * h;
     const int sx = gx + a.crop, sy = gy + a.crop;
-    uint8_t* o = a.outs[im] + ((long long)(t.out_y - a.out_row0 + gy) * a.out_w + t.out_x + gx) * a.c;
+    uint8_t* o = a.outs[im] + ((long long)(t.out_y - a.out_row0 + gy) * a.out_ws[im] + t.out_x + gx) * a.c;
     const TP* b0 = reinterpret_cast<const TP*>(static_cast<const char*>(a.planar3) + (long long)t.slot0 * a.slot_stride);
     float v[3];
     if (!a.tta)
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void postproc_tiles(const PostArgs a)
         for (int j = 0; j < 4; j++)
         {
             const int yy = ay0 + clampi(by - 1 + j, ah);
-            const uint8_t* rp = a.in_imgs[im] + ((long long)yy * a.in_w + ax0) * 4 + 3;
+            const uint8_t* rp = a.in_imgs[im] + ((long long)yy * a.in_ws[im] + ax0) * 4 + 3;
             rows[j] = (float)rp[clampi(bx - 1, aw) * 4] * cx[0] + (float)rp[clampi(bx, aw) * 4] * cx[1] +
                       (float)rp[clampi(bx + 1, aw) * 4] * cx[2] + (float)rp[clampi(bx + 2, aw) * 4] * cx[3];
         }
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
             for (int j = 0; j < 4; j++)
             {
                 const int yy = ay0 + clampi(by - 1 + j, ah);
-                const uint8_t* rp = a.in_imgs[im] + ((long long)yy * a.in_w + ax0) * 4 + 3;
+                const uint8_t* rp = a.in_imgs[im] + ((long long)yy * a.in_ws[im] + ax0) * 4 + 3;
                 rows[j] = (float)rp[clampi(bx - 1, aw) * 4] * cx[0] + (float)rp[clampi(bx, aw) * 4] * cx[1] +
                           (float)rp[clampi(bx + 1, aw) * 4] * cx[2] + (float)rp[clampi(bx + 2, aw) * 4] * cx[3];
             }
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256) void postproc_tiles_lds(const PostArgs a)
     for (int i = tid; i < ny * nd; i += 256)
     {
         const int r = i / nd, d = i - r * nd;
-        uint8_t* o = a.outs[im] + ((long long)(t.out_y - a.out_row0 + gy0 + r) * a.out_w + t.out_x + gx0) * a.c;
+        uint8_t* o = a.outs[im] + ((long long)(t.out_y - a.out_row0 + gy0 + r) * a.out_ws[im] + t.out_x + gx0) * a.c;
         reinterpret_cast<uint32_t*>(o)[d] = reinterpret_cast<const uint32_t*>(&ob[r][0])[d];
     }
 }

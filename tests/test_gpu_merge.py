@@ -59,11 +59,43 @@ def test_merged_images_equal_lone_calls(paths, oracle_net, c, tta, T):
         run_threads(12, work)
         for i in range(36):
             assert np.array_equal(outs[i], lone[i]), i
-        nb, ni, widest = s.get_stat("merged_batches"), s.get_stat("merged_images"), s.get_stat("merged_widest")
-        print("c=%d tta=%d: %d images in %d merged batches, widest %d" % (c, tta, ni, nb, widest))
-        assert ni == 36 and nb < 36 and widest >= 2
+        nb, ni, widest, mixed = s.get_stat("merged_batches"), s.get_stat("merged_images"), s.get_stat("merged_widest"), s.get_stat("merged_mixed")
+        print("c=%d tta=%d: %d images in %d merged batches (%d of them with images of both sizes), widest %d" % (c, tta, ni, nb, mixed, widest))
+        assert ni == 36 and nb < 36 and widest >= 2 and mixed >= 1
         ref = oracle_net.process(imgs[5], T, tta=bool(tta))
         assert np.abs(outs[5].astype(int) - ref.astype(int)).max() <= 1
+    finally:
+        s.close()
+
+
+def test_merged_batches_of_many_different_sizes(paths):
+    """A directory of thumbnails: 40 images of 20 different sizes (1 .. 9 tiles each, some smaller than the halo, one column / one row
+    ones) from 10 caller threads.  Batches form across sizes -- their tile and work-item tables are built on the fly (Engine::enqueue_mixed)
+    -- and every image equals its lone call; with option merge_mixed = 0 only images of one size share a batch, same bytes."""
+    s = R.RealSR(0)
+    try:
+        s.load(*paths)
+        s.tilesize = 32
+        rng = np.random.default_rng(7)
+        sizes = [(int(rng.integers(3, 100)), int(rng.integers(3, 100))) for _ in range(18)] + [(97, 5), (4, 90)]
+        imgs = [synth.make_image(700 + i, *sizes[i % 20]) for i in range(40)]
+        s.set_option("merge", 1)
+        lone = [s.process(im) for im in imgs]
+        for mixed in (1, 0):
+            s.set_option("merge", 16)
+            s.set_option("merge_mixed", mixed)
+            m0, b0 = s.get_stat("merged_mixed"), s.get_stat("merged_batches")
+            outs = [None] * 40
+
+            def work(t):
+                for i in range(4 * t, 4 * t + 4):
+                    outs[i] = s.process(imgs[i], push_params=False)
+            run_threads(10, work)
+            for i in range(40):
+                assert outs[i].shape == lone[i].shape and np.array_equal(outs[i], lone[i]), (mixed, i, sizes[i % 20])
+            nm, nb = s.get_stat("merged_mixed") - m0, s.get_stat("merged_batches") - b0
+            print("merge_mixed=%d: 40 images of 20 sizes in %d batches, %d of them mixed" % (mixed, nb, nm))
+            assert (nm >= 1 and nb < 40) if mixed else nm == 0
     finally:
         s.close()
 

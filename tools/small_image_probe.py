@@ -85,4 +85,29 @@ for (w, h, T) in ((128, 128, 128), (200, 200, 200), (320, 240, 200), (512, 512, 
         a.set_option("merge", merge); a.tilesize = T
         ms, mp = bench([a], 16, w, h, 64)
         print("  %dx%d tile %d merge=%2d: %.2f ms per image, %.1f Mpix/s (merge width %d)" % (w, h, T, merge, ms, mp, a.get_stat("merged_widest")), flush=True)
+# a directory of thumbnails: 64 images of 16 different sizes (48 .. 320 pixels a side), 16 caller threads, tile 200, device-resident
+import numpy as np
+rng = np.random.default_rng(3)
+sizes = [(int(rng.integers(48, 321)), int(rng.integers(48, 321))) for _ in range(16)]
+d_ins = [torch.from_numpy(synth.make_image(900 + i, *sizes[i % 16])).cuda() for i in range(64)]
+d_outs = [torch.empty((sizes[i % 16][1] * 4, sizes[i % 16][0] * 4, 3), dtype=torch.uint8, device="cuda") for i in range(64)]
+mpix = sum(16.0 * w * h for (w, h) in sizes) * 4 / 1e6
+a.tilesize = 200
+print("64 images of 16 different sizes (48 .. 320 px a side, %.1f Mpix of output), tile 200, 16 caller threads:" % mpix)
+for label, merge, mixed in (("not merged", 1, 1), ("merged, one size per batch", 16, 0), ("merged across sizes", 16, 1)):
+    a.set_option("merge", merge); a.set_option("merge_mixed", mixed)
+    b0, m0 = a.get_stat("merged_batches"), a.get_stat("merged_mixed")
+
+    def work(t):
+        for i in range(4 * t, 4 * t + 4):
+            a.process_device(d_ins[i].data_ptr(), sizes[i % 16][0], sizes[i % 16][1], 3, d_outs[i].data_ptr())
+    for rep in range(3):
+        if rep == 1:
+            torch.cuda.synchronize(); t0 = time.time(); b0, m0 = a.get_stat("merged_batches"), a.get_stat("merged_mixed")
+        th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+        [x.start() for x in th]; [x.join() for x in th]
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / 2
+    print("  %-28s %.1f ms per pass = %.1f Mpix/s  (%d batches per pass, %d mixed)" % (label, dt * 1e3, mpix / dt, (a.get_stat("merged_batches") - b0) / 2,
+                                                                                     (a.get_stat("merged_mixed") - m0) / 2), flush=True)
 a.close()

@@ -256,7 +256,8 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *   "merge"             small images of concurrent rsr_process / synchronous rsr_process_device calls walk the network as ONE tile batch, up
  *                       to this many per batch (default 16 = the most; 1 = off: the calls queue up on the compute stream).  An image is
  *                       small when its tiles are fewer than a quarter of "merge_target_items" (default 4096) 16 x 32 blocks -- 256 x 256
- *                       at tile 128 is 200; a 1080p frame, 5,900, fills the chip by itself.  Output bytes unchanged
+ *                       at tile 128 is 200; a 1080p frame, 5,900, fills the chip by itself.  The images of a batch may differ in
+ *                       size ("merge_mixed" 0: only images of one size share a batch).  Output bytes unchanged
  *   "bgr"               1: the caller's images are BGR(A) (the reference's Windows build: WIC decodes to BGR, realsr.cpp:188-206,
  *                       497-515, realsr_preproc.comp:17-21); the network always sees RGB.  Default 0 = RGB(A)
  *   "max_lanes"         rsr_process calls in flight per context (default 4); "chunk_mb": download chunk for pageable
@@ -287,8 +288,8 @@ int rsr_set_option(rsr_ctx* ctx, const char* key, long long value);
  *                       fits ONE batch of 60 slots under the default 64 GiB budget; max_workspace_mb splits it), "plans" cached plans
  *   "plan_items_lr" / "plan_items_2x" / "plan_items_4x"  work items (16 x 32 pixel blocks) of that plan per resolution level and image: what the
  *                       conv launches of a frame actually walk (blocks that only feed cropped pixels are left out, narrow last columns folded)
- *   "merged_batches" / "merged_images" / "merged_widest"  tile batches that merged small images of concurrent calls, the images they
- *                       carried, the widest one; "device_direct": rsr_process_device calls that ran on the caller's own stream
+ *   "merged_batches" / "merged_images" / "merged_widest" / "merged_mixed"  tile batches that merged small images of concurrent calls, the
+ *                       images they carried, the widest one, those whose images differed in size; "device_direct": rsr_process_device calls that ran on the caller's own stream
  *   "workspace_mb"      device memory the workspace holds, "ws_clamp_mb" the bound a failed allocation left behind (-1 = none)
  *   "lanes", "lane_in_mb", "lane_out_mb"   rsr_process lanes created so far and the device image buffers they hold (a member of
  *                       rsr_process_group allocates only the output rows of its tile range)

@@ -13,8 +13,8 @@
 //     (a few hundred microseconds of host time) and the GPU executes them in that order.  A lane's upload runs
 //     ahead of, and its download behind, the other lanes' kernels: H2D(k+1) | kernels(k) | D2H(k-1) overlap;
 //   * SMALL images of concurrent calls are MERGED: a 256 x 256 image is 200 blocks for 256 CUs -- every one of the 352
-//     launches costs its fixed ~14 us whatever it carries -- so calls whose image is small and of the same geometry
-//     are combined into ONE tile batch (up to kMaxMerge images, Engine::submit_merged): the caller that finds no leader
+//     launches costs its fixed ~14 us whatever it carries -- so calls whose image is small (any small size; same channel
+//     count) are combined into ONE tile batch (up to kMaxMerge images, Engine::submit_merged): the caller that finds no leader
 //     becomes one, waits until the previous merged batch is half way through the network (while it waits, further calls
 //     queue up; its own launches are then enqueued underneath the second half), takes the queued calls of its
 //     geometry and enqueues them as one batch; the others sleep until

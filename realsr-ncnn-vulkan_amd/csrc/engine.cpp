@@ -1289,6 +1289,16 @@ int Engine::run_group(MergeReq* const* g, int n)
     {
         rc = enqueue_mixed(g, n, stream, merge_mid);
         if (rc == RSR_OK) merged_mixed++;
+        else if (rc == RSR_E_NOMEM)
+        { // the batch does not fit the workspace budget / the device right now: one image at a time (each call bounds and halves its own batch)
+            (void)hipStreamSynchronize(stream);
+            for (int i = 0; i < n; i++)
+            {
+                rc = enqueue_images(&ins[i], &outs[i], 1, g[i]->w, g[i]->h, g[i]->c, stream, 0, -1, nullptr, nullptr, i == n - 1 ? merge_mid : nullptr,
+                                    merge_width(g[i]->w, g[i]->h, g[i]->c));
+                if (rc != RSR_OK) break;
+            }
+        }
     }
     if (rc == RSR_OK)
         for (int i = 0; i < n && rc == RSR_OK; i++)

@@ -1233,10 +1233,6 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
 }
 
 // ---- merging small images across calls (engine.h) ---------------------------------------------
-// How many images of this geometry one merged batch may take: 1 = the image is not small (more than a quarter of the work items a
-// batch aims at: a few launches' worth of blocks per CU by itself) or merging is off; else as many as keep the batch at
-// `merge_target_items` LR-level work items (16 x 32 blocks; x8 under TTA), at most merge_max.  ONE plan of that width serves every
-// narrower batch (enqueue_images: plan_nimg).
 // LR-level work items (16 x 32 blocks; x8 under TTA) of a w x h image at the current tile size; stops counting beyond `limit`
 long long Engine::image_items(int w, int h, long long limit) const
 {
@@ -1253,6 +1249,10 @@ long long Engine::image_items(int w, int h, long long limit) const
     return items;
 }
 
+// How many images of this geometry one merged batch may take: 1 = the image is not small (more than a quarter of the work items a
+// batch aims at: a few launches' worth of blocks per CU by itself) or merging is off; else as many as keep the batch at
+// `merge_target_items` LR-level work items, at most merge_max.  ONE cached plan of that width serves every narrower batch of this
+// geometry (enqueue_images: plan_nimg).
 int Engine::merge_width(int w, int h, int c) const
 {
     (void)c;
@@ -1262,7 +1262,8 @@ int Engine::merge_width(int w, int h, int c) const
     return int(std::max<long long>(1, std::min<long long>(std::min(merge_max, kMaxMerge), merge_target_items / std::max<long long>(items, 1))));
 }
 
-// Enqueue the images of g[0..n) (one geometry) as ONE tile batch; records every request's ev_done behind it.
+// Enqueue the images of g[0..n) as ONE tile batch (one geometry: the cached plan; several: tables built on the fly); records every
+// request's ev_done behind it.
 int Engine::run_group(MergeReq* const* g, int n)
 {
     std::lock_guard<std::mutex> lk(mu);
@@ -1356,17 +1357,19 @@ int Engine::submit_merged(MergeReq& r)
     r.lead = false;
     while (!r.done)
     {
-        // Throttle: the next batch is formed when the previous one is HALF WAY through the network -- its ~350 launches (1 - 2 ms of
-        // host time) are then enqueued underneath the second half, the GPU never waits, and while this thread waits further calls queue
-        // up behind it: that is what fills a batch (1.5 batch times of arrivals; measured in profiles/r06_small_images.txt).
+        // Throttle: the next batch is formed when the previous one is NEARLY through the network (launch_batch: an event behind the RDB
+        // that leaves about half an image's worth of network ahead) -- its ~350 launches (1 - 2 ms of host time) are then enqueued
+        // underneath the rest, the GPU never waits, and while this thread waits further calls queue up behind it: that is what fills a
+        // batch (measured in profiles/r06_small_images.txt).
         hipEvent_t wait_ev = merge_mid_used ? merge_mid : nullptr;
         lk.unlock();
         if (wait_ev) (void)hipEventSynchronize(wait_ev);
         lk.lock();
         // Calls that are known to be on their way (their image is still being uploaded) are worth a moment: a batch costs milliseconds,
         // they arrive within microseconds -- 16 callers that start together would otherwise open with batches of 1, 1, 7, 7.
-        for (int spins = 0; merge_inbound.load() > 0 && int(cq.size()) < kMaxMerge && spins < 8; spins++)
-            cq_cv.wait_for(lk, std::chrono::microseconds(50));
+        for (const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+             merge_inbound.load() > 0 && int(cq.size()) < kMaxMerge && std::chrono::steady_clock::now() < deadline;)
+            cq_cv.wait_until(lk, deadline); // (every arrival notifies)
         // The batch: the head of the queue and, in order of arrival, the calls behind it that fit -- same channel count and tile size (one
         // preproc / conv_last / postproc launch serves all), images of ANY small size (option merge_mixed 0: of the head's size only) --
         // while the batch stays within merge_target_items work items and merge_max images.
@@ -1397,6 +1400,7 @@ int Engine::submit_merged(MergeReq& r)
             std::fprintf(stderr, "merge: t=%.3f ms take %d of %d waiting (width %d, previous batch of %d %s, %d inbound)\n",
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), take, n, width, merge_last_n,
                          (merge_done && hipEventQuery(merge_done) == hipErrorNotReady) ? "running" : "done", merge_inbound.load());
+        (void)hipGetLastError();
         lk.unlock();
         const int rc = run_group(g, take);
         const std::string why = rc == RSR_OK ? std::string() : std::string(last_error());
@@ -1508,9 +1512,13 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
             if (n) --*n;
             n = nullptr;
         }
-    } inbound{mergeable ? &merge_inbound : nullptr};
-    if (mergeable) ++merge_inbound;
+    } inbound{nullptr};
     Lane* L = acquire_lane();
+    if (mergeable)
+    { // counted from here: a call that is still waiting for a lane is not "on its way" (lanes free up when batches complete)
+        ++merge_inbound;
+        inbound.n = &merge_inbound;
+    }
     // Whatever way this call ends, nothing of it may still be in flight when the lane -- and with it the caller's `in` / `out`
     // -- is handed back: a HIP failure half way must not turn into a use-after-free of the lane buffers by the next caller.
     struct Release

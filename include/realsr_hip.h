@@ -70,6 +70,12 @@ int rsr_set_params(rsr_ctx* ctx, int scale, int tilesize, int prepadding);
  * D2H; returns when `out` is complete. */
 int rsr_process(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* out);
 
+/* n images in one call (no reference counterpart: main.cpp's proc threads call process() once per image, :311-331).  Every image is
+ * what rsr_process would make of it; up to max_lanes of them are in flight at once on helper threads of the call, so that SMALL
+ * images share tile batches (option "merge") without the host having to be multi-threaded.  rcs (may be NULL) receives the code of
+ * every image; the return value is the first failure (0 = all ok). */
+int rsr_process_many(rsr_ctx* ctx, int n, const uint8_t* const* in, const int* w, const int* h, const int* c, uint8_t* const* out, int* rcs);
+
 /* Same computation with both images already resident in this context's device memory
  * (what the reference keeps in VkMat in_gpu/out_gpu, realsr.cpp:211-233, minus the PCIe hops).
  * `stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous when a stream is

@@ -26,7 +26,7 @@ EXPORTS = [
     "rsr_set_option", "rsr_last_error", "rsr_version", "rsr_host_alloc", "rsr_host_free",
     "rsr_set_progress_callback", "rsr_conv3x3_res", "rsr_create_group", "rsr_group_transport", "rsr_process_rows",
     "rsr_process_group", "rsr_device_memory", "rsr_process_tiles", "rsr_tile_partition", "rsr_rccl_probe", "rsr_get_stat",
-    "rsr_net_forward_f32", "rsr_conv3x3_res_precise",
+    "rsr_net_forward_f32", "rsr_conv3x3_res_precise", "rsr_process_many",
 ]
 
 RSR_OK, RSR_E_ARG, RSR_E_IO, RSR_E_FORMAT, RSR_E_GRAPH, RSR_E_DEVICE, RSR_E_STATE, RSR_E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -100,6 +100,7 @@ def lib():
     L.rsr_net_forward.argtypes = [vp, vp, ip, ip, vp]
     L.rsr_conv3x3.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp]
     L.rsr_conv3x3_res.argtypes = [vp, vp, ip, ip, ip, vp, vp, ip, C.c_float, ip, vp, C.c_float, vp]
+    L.rsr_process_many.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(vp), C.POINTER(ip)]
     L.rsr_net_forward_f32.argtypes = [vp, vp, ip, ip, vp]
     L.rsr_conv3x3_res_precise.argtypes = [vp, vp, vp, ip, ip, ip, vp, vp, C.c_float, ip, vp, vp, C.c_float, vp, vp]
     L.rsr_create_group.argtypes = [C.POINTER(vp), C.POINTER(ip), ip, ip, cp, cp]
@@ -246,6 +247,21 @@ class RealSR:
         assert out.shape == (h * self.scale, w * self.scale, c) and out.dtype == np.uint8 and out.flags.c_contiguous
         self._ck(self._L.rsr_process(self._h, _p(img), w, h, c, _p(out)))
         return out
+
+    def process_many(self, imgs):
+        """rsr_process_many: a list of uint8 HWC images in ONE call (small ones share tile batches); returns the list of outputs."""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in imgs]
+        n = len(imgs)
+        outs = [np.empty((im.shape[0] * self.scale, im.shape[1] * self.scale, im.shape[2]), dtype=np.uint8) for im in imgs]
+        self._push_params()
+        ins_p = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        outs_p = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ws = (C.c_int * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_int * n)(*[im.shape[0] for im in imgs])
+        cs = (C.c_int * n)(*[im.shape[2] for im in imgs])
+        rcs = (C.c_int * n)()
+        self._ck(self._L.rsr_process_many(self._h, n, ins_p, ws, hs, cs, outs_p, rcs))
+        return outs
 
     def process_device(self, d_in, w, h, c, d_out, stream=None):
         """d_in/d_out: integer device pointers (e.g. torch tensor .data_ptr())."""

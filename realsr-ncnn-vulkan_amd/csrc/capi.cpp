@@ -123,6 +123,46 @@ int rsr_process(rsr_ctx* ctx, const uint8_t* in, int w, int h, int c, uint8_t* o
     return ctx->e.process_host(in, w, h, c, out);
 }
 
+int rsr_process_many(rsr_ctx* ctx, int n, const uint8_t* const* in, const int* w, const int* h, const int* c, uint8_t* const* out, int* rcs)
+{
+    if (!ctx || n < 0 || (n > 0 && (!in || !w || !h || !c || !out))) return RSR_E_ARG;
+    if (n == 0) return RSR_OK;
+    // One caller thread, many images: each image is an ordinary rsr_process call on a helper thread (as many in flight as the context has
+    // lanes), so that small images meet in merged tile batches exactly as the calls of a multi-threaded host do (engine.h).
+    int nthreads = 1;
+    {
+        std::lock_guard<std::mutex> ll(ctx->e.lane_mu);
+        nthreads = std::max(1, std::min(n, ctx->e.max_lanes));
+    }
+    std::vector<int> codes(size_t(n), RSR_OK);
+    std::vector<std::string> msgs{size_t(n)};
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (int i = next++; i < n; i = next++)
+        {
+            codes[size_t(i)] = ctx->e.process_host(in[i], w[i], h[i], c[i], out[i]);
+            if (codes[size_t(i)] != RSR_OK) msgs[size_t(i)] = rsr::last_error();
+        }
+    };
+    std::vector<std::thread> helpers;
+    try
+    {
+        for (int t = 1; t < nthreads; t++) helpers.emplace_back(work);
+    }
+    catch (...) // thread limit / no memory: the images the missing helpers would have taken are done by the threads that exist
+    {
+    }
+    work(); // the calling thread takes its share
+    for (std::thread& t : helpers) t.join();
+    int first = RSR_OK;
+    for (int i = 0; i < n; i++)
+    {
+        if (rcs) rcs[i] = codes[size_t(i)];
+        if (first == RSR_OK && codes[size_t(i)] != RSR_OK) first = Engine::fail(codes[size_t(i)], "image " + std::to_string(i) + ": " + msgs[size_t(i)]);
+    }
+    return first;
+}
+
 int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void* d_out, void* stream)
 {
     if (!ctx) return RSR_E_ARG;

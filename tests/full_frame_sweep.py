@@ -4,7 +4,8 @@ check the default `-m gpu` run does (tests/oracle_pool.py check_frame_golden).
 The oracle frames are the ones tests/golden/make_frames.py computes and caches under tests/golden/_full/<name>.npy (git-ignored,
 100 - 400 MB each, ~10 / ~40 / ~95 minutes of CPU per frame): they travel to the GPU box with the snapshot when `.gpurunignore` lets
 them.  Run on the MI355X box:
-    python tests/full_frame_sweep.py c5 [c2] [c3]            -> one line per tile + a summary; exit code 1 on any |diff| > 1
+    python tests/full_frame_sweep.py c5 [c2] [c3] [c2:p ...]  -> one line per tile + a summary; exit code 1 on any |diff| > 1
+(a name with the suffix ":p" runs the frame in precise mode, rsr_set_option precise 1)
 Logs of such runs are kept under profiles/ (r05_c5_sweep.txt)."""
 import hashlib
 import os
@@ -25,6 +26,8 @@ def main(names):
     from realsr_ncnn_vulkan_amd import synth
     bad = 0
     for name in names:
+        precise = name.endswith(":p")
+        name = name.split(":")[0]
         mdir, wseed, iseed, w, h, T, tta = make_frames.FRAMES[name]
         full = os.path.join(HERE, "golden", "_full", name + ".npy")
         if not os.path.exists(full):
@@ -41,12 +44,14 @@ def main(names):
         sr = R.RealSR(0, tta_mode=bool(tta))
         sr.load(pp, bp)
         sr.tilesize = T
+        if precise:
+            sr.set_option("precise", 1)
         out = sr.process(img)
         sr.close()
         xt, yt = (w + T - 1) // T, (h + T - 1) // T
         worst, ndiff, total, bad_tiles = 0, 0, 0, 0
-        print("%s: %s, %dx%d, tile %d%s: %d x %d tiles, every output pixel against the oracle's frame (computed by tests/golden/make_frames.py)" % (
-            name.upper(), mdir, w, h, T, ", TTA x8" if tta else "", xt, yt))
+        print("%s: %s, %dx%d, tile %d%s%s: %d x %d tiles, every output pixel against the oracle's frame (computed by tests/golden/make_frames.py)" % (
+            name.upper(), mdir, w, h, T, ", TTA x8" if tta else "", ", PRECISE mode" if precise else "", xt, yt))
         for yi in range(yt):
             for xi in range(xt):
                 y0, x0 = 4 * yi * T, 4 * xi * T

@@ -100,6 +100,44 @@ def test_merged_batches_of_many_different_sizes(paths):
         s.close()
 
 
+def test_process_many_from_one_thread(paths, oracle_net):
+    """rsr_process_many: 30 images of 6 sizes (RGB and RGBA mixed: they never share a batch) handed over in ONE call by ONE thread --
+    merged batches form among the call's helper threads, every output equals the lone rsr_process call's; a bad image in the list fails
+    with its index and the others are still done; n = 0 is a no-op."""
+    s = R.RealSR(0)
+    try:
+        s.load(*paths)
+        s.tilesize = 32
+        sizes = [(40, 30, 3), (33, 21, 4), (64, 64, 3), (20, 70, 3), (50, 50, 4), (90, 16, 3)]
+        imgs = [synth.make_image(800 + i, *sizes[i % 6]) for i in range(30)]
+        s.set_option("merge", 1)
+        lone = [s.process(im) for im in imgs]
+        s.set_option("merge", 16)
+        b0 = s.get_stat("merged_batches")
+        outs = s.process_many(imgs)
+        assert len(outs) == 30 and all(np.array_equal(a, b) for a, b in zip(outs, lone))
+        nb = s.get_stat("merged_batches") - b0
+        print("process_many: 30 images in %d merged batches" % nb)
+        assert nb < 30
+        assert s.process_many([]) == []
+        ref = oracle_net.process(imgs[7], 32)
+        assert np.abs(outs[7].astype(int) - ref.astype(int)).max() <= 1
+        L = R.lib()
+        import ctypes as C
+        n = 3
+        good = [imgs[0], imgs[2], imgs[3]]
+        o = [np.zeros_like(lone[0]), np.zeros_like(lone[2]), np.zeros_like(lone[3])]
+        ins_p = (C.c_void_p * n)(good[0].ctypes.data, None, good[2].ctypes.data)  # image 1: null pointer
+        outs_p = (C.c_void_p * n)(*[x.ctypes.data for x in o])
+        ws, hs, cs = (C.c_int * n)(40, 64, 20), (C.c_int * n)(30, 64, 70), (C.c_int * n)(3, 3, 3)
+        rcs = (C.c_int * n)()
+        rc = L.rsr_process_many(s._h, n, ins_p, ws, hs, cs, outs_p, rcs)
+        assert rc == R.RSR_E_ARG and list(rcs) == [0, R.RSR_E_ARG, 0] and b"image 1" in L.rsr_last_error(s._h)
+        assert np.array_equal(o[0], lone[0]) and np.array_equal(o[2], lone[3])
+    finally:
+        s.close()
+
+
 def test_merged_device_api_and_precise_mode(paths):
     """The device API (synchronous rsr_process_device calls from 8 threads) merges too; precise mode (lo planes in the slots) likewise."""
     import torch

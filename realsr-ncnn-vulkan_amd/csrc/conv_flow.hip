@@ -444,9 +444,9 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     constexpr bool PRE2 = (EPI == 2 || EPI == 4) && NTW == 1; // (EPI 5 fetches lo rows at the start of its epilogue anyway: nothing to gain, 16 VGPRs to lose)
     u32x4 r2q[PRE2 ? 2 : 1][NTW][2]; // rows 0-1, then rows 2-3
 #ifndef RSR_PREC_PRE
-#define RSR_PREC_PRE 2 // EPI 4: lo rows of residual 1 fetched one half-stage ahead of the epilogue (the rest at its start; 4 costs a spilled dword and is no faster: profiles/r06_precise_cost.txt)
+#define RSR_PREC_PRE 1 // EPI 4: lo rows of residual 1 fetched one half-stage ahead of the epilogue (the rest at its start).  1: no spill; 2 spills two dwords and measures the same, 3 / 4 spill a row (profiles/r06_precise_cost.txt)
 #endif
-    u32x2 l1q[EPI == 4 ? 4 : 1][2];  // EPI 4: the four lo rows of residual 1
+    u32x4 l1q[EPI == 4 ? 4 : 1];     // EPI 4: the four lo rows of residual 1
     // Out-of-image lanes / rows read zeros through the buffer range check, like row_store drops them.
     auto res2_row = [&](u32x4 (&dst)[2], const OutDesc& o, int rr, int n) {
         const int y = o.y0 + rr;
@@ -462,19 +462,15 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     };
     // the same fetch from the planes `off` bytes behind those of `s` (EPI 4 / 5: the lo planes of a residual; off == 0: there are none,
     // the null resource returns zeros)
-    // A lo plane has the geometry of its hi plane at HALF the bytes (16 channels x 1 B per pixel, plane stride / 2): every byte offset
-    // of the hi addressing -- lane, row, plane, the range limit, the out-of-range sentinel -- is simply halved.
-    auto lo_row = [&](const PlaneSrc& s, long long off, u32x2 (&dst)[2], const OutDesc& o, int rr, int n) {
+    // The lo bytes of an n-tile's TWO planes share one "pair plane" with the geometry of a hi plane (32 B per pixel): lane (pixel, half)
+    // owns the 16 bytes at pixel * 32 + half * 16 = [its 8 channels of plane 0 | its 8 channels of plane 1] -- the hi addressing with
+    // the n-tile in the place of the plane, one 1-KiB load / store per row and n-tile (the layout is private to these epilogues).
+    auto lo_row = [&](const PlaneSrc& s, long long off, u32x4& dst, const OutDesc& o, int rr, int n) {
         const int y = o.y0 + rr;
-        const unsigned hstride = unsigned(s.plane_stride) >> 1;
-        char* ub = uniform_ptr(const_cast<char*>(plane_ptr(s, o.slot, 0)) + off + (long long)(ntw0 * 2) * hstride);
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-        {
-            const unsigned poff = unsigned(n * 2 + p) * hstride;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, off ? int((o.lim >> 1) + poff) : 0, 0x00020000);
-            dst[p] = __builtin_amdgcn_raw_buffer_load_b64(rs, int(unsigned(o.voff) >> 1), int(unsigned(y) * unsigned(o.W * (kFPx / 2)) + poff), 0);
-        }
+        const unsigned pstride = unsigned(s.plane_stride);
+        char* ub = uniform_ptr(const_cast<char*>(plane_ptr(s, o.slot, 0)) + off + (long long)(ntw0 + n) * pstride);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, off ? int(o.lim) : 0, 0x00020000);
+        dst = __builtin_amdgcn_raw_buffer_load_b128(rs, o.voff, int(unsigned(y) * unsigned(o.W * kFPx)), 0);
     };
     auto res2_prefetch = [&](const WorkItem& w, int row0) { // rows row0, row0 + 1
         if (!PRE2) return;
@@ -556,23 +552,24 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
     // EPI 4 / 5, one row of one n-tile: everything in fp32, one rounding (see the template comment).  l1 / r2h / r2l: this lane's 16
     // bytes per plane of residual 1's lo planes, of residual 2 and of residual 2's lo planes (the latter two: EPI 5 only).
     constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
-    auto row_emit4 = [&](const f32x16& acc, const OutDesc& o, int rr, int n, const u32x2 (&l1)[2], const u32x4 (&r2h)[2], const u32x2 (&r2l)[2]) {
+    auto row_emit4 = [&](const f32x16& acc, const OutDesc& o, int rr, int n, const u32x4& l1, const u32x4 (&r2h)[2], const u32x4& r2l) {
         const int y = o.y0 + rr;
         char* ub = uniform_ptr(o.base);
-        const unsigned pstride = unsigned(a.out16.plane_stride), hstride = pstride >> 1;
-        char* ul = uniform_ptr(const_cast<char*>(plane_ptr(a.out16, o.slot, 0)) + a.out_lo_off + (long long)(ntw0 * 2) * hstride);
+        const unsigned pstride = unsigned(a.out16.plane_stride);
+        char* ul = uniform_ptr(const_cast<char*>(plane_ptr(a.out16, o.slot, 0)) + a.out_lo_off + (long long)(ntw0 + n) * pstride);
+        const unsigned rowoff = unsigned(y) * unsigned(o.W * kFPx);
+        u32x4 vl;
 #pragma unroll
         for (int p = 0; p < 2; p++)
         {
-            // four values at a time (one dword of each lo plane): the 168-VGPR budget has no room for a whole decoded row
+            // four values at a time (one dword of the lo bytes): the 168-VGPR budget has no room for a whole decoded row
             half8 vh;
-            u32x2 vl;
             const half8 r = __builtin_bit_cast(half8, r2h[p]);
 #pragma unroll
             for (int k = 0; k < 2; k++)
             {
                 float f[4], lf[4];
-                bf8x4_to_f32(l1[p][k], lf);
+                bf8x4_to_f32(l1[p * 2 + k], lf);
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                 {
@@ -582,7 +579,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 }
                 if (EPI == 5)
                 {
-                    bf8x4_to_f32(r2l[p][k], lf);
+                    bf8x4_to_f32(r2l[p * 2 + k], lf);
 #pragma unroll
                     for (int e = 0; e < 4; e++) f[e] = __builtin_fmaf(lf[e], kLoInv, __builtin_fmaf(f[e], a.s2, (float)r[k * 4 + e]));
                 }
@@ -596,16 +593,16 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 }
                 int wq = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], 0, false);
                 wq = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], wq, true);
-                vl[k] = unsigned(wq);
+                vl[p * 2 + k] = unsigned(wq);
             }
-            const unsigned poff = unsigned(n * 2 + p) * pstride, loff = unsigned(n * 2 + p) * hstride;
-            const unsigned rowoff = unsigned(y) * unsigned(o.W * kFPx);
+            const unsigned poff = unsigned(n * 2 + p) * pstride;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, o.live ? int(o.lim + poff) : 0, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vh), rs, o.voff + int(rowoff + poff), 0, 0);
-            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(ul, 0, (o.live && a.out_lo_off) ? int((o.lim >> 1) + loff) : 0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b64(vl, rl, int(unsigned(o.voff) >> 1) + int((rowoff >> 1) + loff), 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(ul, 0, (o.live && a.out_lo_off) ? int(o.lim) : 0, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(vl, rl, o.voff + int(rowoff), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
     // conv_last (EPI 0): channels 0..2 of n-tile 0 -> planar fp16 [3][H][W] (the reference's `output` blob, consumed by
     // postproc_tiles), or -- non-TTA RGB -- straight into the uint8 image: realsr_postproc.comp:62-83 on the value rounded to
@@ -1099,7 +1096,7 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
                 else
                 {
                     u32x4 rh[2][2];
-                    u32x2 la[2][2], ra[2][2];
+                    u32x4 la[2], ra[2];
 #pragma unroll
                     for (int h2 = 0; h2 < 2; h2++)
                     {

@@ -1810,10 +1810,14 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
     std::vector<uint16_t> hin(size_t(np + (in_lo ? npo : 0)) * ipl, 0), hout(size_t(npo) * (out_lo ? 2 : 1) * opx * size_t(pch), 0);
     for (int ch = 0; ch < cin; ch++)
         for (size_t p = 0; p < ipx; p++) hin[size_t(ch / pch) * ipl + kGuard / 2 + p * size_t(pch) + size_t(ch % pch)] = in[size_t(ch) * ipx + p];
+    // (the lo bytes of an n-tile's two planes share one "pair plane" of the hi geometry: [pixel][half][plane][8 channels], conv_flow.hip lo_row)
+    auto lo_index = [&](int ch, size_t p, size_t pair_stride) {
+        return size_t(ch / 32) * pair_stride + p * 32 + size_t((ch % 16) / 8) * 16 + size_t((ch % 32) / 16) * 8 + size_t(ch % 8);
+    };
     auto put_lo = [&](std::vector<uint16_t>& buf, size_t lo_off, const uint8_t* lo) {
         unsigned char* b = reinterpret_cast<unsigned char*>(buf.data()) + kGuard + lo_off;
         for (int ch = 0; ch < cout; ch++)
-            for (size_t p = 0; p < ipx; p++) b[size_t(ch / pch) * (ipl_b / 2) + p * size_t(pch) + size_t(ch % pch)] = lo[size_t(ch) * ipx + p];
+            for (size_t p = 0; p < ipx; p++) b[lo_index(ch, p, ipl_b)] = lo[size_t(ch) * ipx + p];
     };
     if (in_lo) put_lo(hin, size_t(np) * ipl_b, in_lo);
     std::vector<uint16_t> hres;
@@ -1907,9 +1911,7 @@ int Engine::conv_test(const uint16_t* in, int cin, int h, int w, int ups, const 
         for (size_t p = 0; p < opx; p++)
         {
             out[size_t(ch) * opx + p] = hout[(size_t(ch / pch) * opx + p) * size_t(pch) + size_t(ch % pch)];
-            if (out_lo)
-                out_lo[size_t(ch) * opx + p] =
-                    reinterpret_cast<const unsigned char*>(hout.data())[size_t(npo) * opl_b + size_t(ch / pch) * (opl_b / 2) + p * size_t(pch) + size_t(ch % pch)];
+            if (out_lo) out_lo[size_t(ch) * opx + p] = reinterpret_cast<const unsigned char*>(hout.data())[size_t(npo) * opl_b + lo_index(ch, p, opl_b)];
         }
     return RSR_OK;
 }

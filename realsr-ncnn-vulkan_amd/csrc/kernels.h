@@ -104,9 +104,11 @@ struct ConvArgs
     // a trunk value v lives as hi = fp16(v) -- the plane every conv reads, unchanged -- and lo = bf8((v - hi) * 2048): the rounding
     // residue as ONE byte (e5m2, i.e. the upper byte of an fp16; scaled so that it never becomes subnormal), 5 more bits of v than
     // hi alone -- as good as an fp16 residue for this network (profiles/r06_storage_emulation.txt).  The residual adds of the
-    // epilogue use hi + lo / 2048.  The lo planes of a tensor ([H][W][16] bytes: the geometry of a hi plane at half the bytes, plane
-    // stride / 2) sit in the same allocation as its hi planes, a fixed number of bytes behind plane 0 (same slot stride): only that
-    // distance travels.  0 = the tensor has no lo planes.
+    // epilogue use hi + lo / 2048.  The lo bytes of a tensor sit in the same allocation as its hi planes, a fixed number of bytes behind
+    // plane 0 (same slot stride): only that distance travels; 0 = the tensor has no lo planes.  Layout: the two planes of an n-tile (32
+    // channels) share one "pair plane" of the hi geometry (32 B per pixel: [half of the 16 channels][plane][8 channels]), so that a lane
+    // of the epilogue reads / writes its 16 lo bytes of a row with ONE 1-KiB-per-wave access at the very offsets of its hi stores
+    // (conv_flow.hip lo_row).  A 64-channel tensor: two pair planes = the room of two hi planes.
     int precise;          // 1: residual forms run the precise epilogue (out16 single-rounded from the fp32 value)
     long long lo1_off;    // lo planes of res1 = res1 + lo1_off bytes
     long long lo2_off;    // lo planes of res2

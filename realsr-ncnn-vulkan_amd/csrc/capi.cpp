@@ -127,6 +127,8 @@ int rsr_process_many(rsr_ctx* ctx, int n, const uint8_t* const* in, const int* w
 {
     if (!ctx || n < 0 || (n > 0 && (!in || !w || !h || !c || !out))) return RSR_E_ARG;
     if (n == 0) return RSR_OK;
+    try
+    {
     // One caller thread, many images: each image is an ordinary rsr_process call on a helper thread (as many in flight as the context has
     // lanes), so that small images meet in merged tile batches exactly as the calls of a multi-threaded host do (engine.h).
     int nthreads = 1;
@@ -161,6 +163,11 @@ int rsr_process_many(rsr_ctx* ctx, int n, const uint8_t* const* in, const int* w
         if (first == RSR_OK && codes[size_t(i)] != RSR_OK) first = Engine::fail(codes[size_t(i)], "image " + std::to_string(i) + ": " + msgs[size_t(i)]);
     }
     return first;
+    }
+    catch (const std::bad_alloc&) // (the bookkeeping vectors; helper threads that could not be started are handled above) -- nothing crosses extern "C"
+    {
+        return Engine::fail(RSR_E_NOMEM, "rsr_process_many: out of host memory");
+    }
 }
 
 int rsr_process_device(rsr_ctx* ctx, const void* d_in, int w, int h, int c, void* d_out, void* stream)

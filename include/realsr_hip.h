@@ -16,7 +16,9 @@
  *     (the reference calls process() concurrently from jobs_proc threads, main.cpp:811-828): every
  *     call owns private device image buffers, pinned staging and a copy stream ("lane", up to
  *     max_lanes in flight, further callers wait); the network kernels of all calls are queued on one
- *     compute stream, so upload(k+1) | kernels(k) | download(k-1) overlap.
+ *     compute stream, so upload(k+1) | kernels(k) | download(k-1) overlap; SMALL images of concurrent
+ *     calls are merged into one tile batch (option "merge"; the reference's "-j 4:4:4 for many small
+ *     images", README.md:61) -- same bytes, shared launches.
  *   - rsr_last_error() reports the CALLING THREAD's most recent failure.
  *   - there is NO CPU fallback: gpuid must name a HIP device; the reference's "-g -1" CPU path
  *     (RealSR::process_cpu) lives only in oracle/ as the parity checker.
@@ -266,7 +268,8 @@ int rsr_get_trace(rsr_ctx* ctx, unsigned long long* out, int n);
  *                       size ("merge_mixed" 0: only images of one size share a batch).  Output bytes unchanged
  *   "bgr"               1: the caller's images are BGR(A) (the reference's Windows build: WIC decodes to BGR, realsr.cpp:188-206,
  *                       497-515, realsr_preproc.comp:17-21); the network always sees RGB.  Default 0 = RGB(A)
- *   "max_lanes"         rsr_process calls in flight per context (default 4); "chunk_mb": download chunk for pageable
+ *   "max_lanes"         rsr_process calls in flight per context (default 16: small images of concurrent calls are merged, the more in
+ *                       flight the fuller the launches); "chunk_mb": download chunk for pageable
  *                       destinations (default 16); "copy_threads": CPU threads per staging copy of a pageable image
  *                       (default 4; 1 = the calling thread alone)
  *   "num_cu"            persistent grid size (profiling aid)

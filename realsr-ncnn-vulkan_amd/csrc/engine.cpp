@@ -1152,18 +1152,22 @@ int Engine::process_device(const void* d_in, int w, int h, int c, void* d_out, h
     hipEvent_t done = nullptr;
     if (!user_stream && sync)
     { // a small image: merged with whatever other calls hand in meanwhile (Engine::submit_merged)
-        int T = 0;
-        {
+        int T = 0, width = 1;
+        long long items = 0;
+        { // (the engine's settings are read under its lock: another thread may be in rsr_set_params / rsr_set_option)
             std::lock_guard<std::mutex> lk(mu);
             if (!loaded) return fail(RSR_E_STATE, "process before load");
             if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
             T = tilesize;
+            width = merge_width(w, h, c);
+            if (width > 1) items = image_items(w, h, merge_target_items);
         }
-        if (merge_width(w, h, c) > 1)
+        if (width > 1)
         {
             MergeReq r;
             r.d_in = d_in; r.d_out = d_out; r.w = w; r.h = h; r.c = c; r.T = T;
-            r.items = image_items(w, h, merge_target_items);
+            r.items = items;
+            r.width = width;
             const int rc = submit_merged(r);
             if (rc != RSR_OK) return rc;
             const hipError_t e = hipEventSynchronize(r.ev_done);
@@ -1256,10 +1260,11 @@ long long Engine::image_items(int w, int h, long long limit) const
 int Engine::merge_width(int w, int h, int c) const
 {
     (void)c;
-    if (merge_max <= 1 || profiling) return 1;
-    const long long items = image_items(w, h, merge_target_items / 4);
-    if (items * 4 > merge_target_items) return 1;
-    return int(std::max<long long>(1, std::min<long long>(std::min(merge_max, kMaxMerge), merge_target_items / std::max<long long>(items, 1))));
+    const int mmax = merge_max, target = merge_target_items;
+    if (mmax <= 1 || profiling) return 1;
+    const long long items = image_items(w, h, target / 4);
+    if (items * 4 > target) return 1;
+    return int(std::max<long long>(1, std::min<long long>(std::min(mmax, kMaxMerge), target / std::max<long long>(items, 1))));
 }
 
 // Enqueue the images of g[0..n) as ONE tile batch (one geometry: the cached plan; several: tables built on the fly); records every
@@ -1376,14 +1381,15 @@ int Engine::submit_merged(MergeReq& r)
         MergeReq* g[kMaxMerge];
         int n = 0;
         const MergeReq* head = cq.front();
-        const int width = merge_mixed ? std::min(merge_max, kMaxMerge) : merge_width(head->w, head->h, head->c);
+        const int width = merge_mixed ? std::min(merge_max.load(), kMaxMerge) : head->width;
+        const long long target = merge_target_items;
         long long items = 0;
         for (MergeReq* q : cq)
         {
             if (n >= width) break;
             if (q->c != head->c || q->T != head->T) continue;
             if (!merge_mixed && (q->w != head->w || q->h != head->h)) continue;
-            if (n > 0 && items + q->items > merge_target_items) continue;
+            if (n > 0 && items + q->items > target) continue;
             g[n++] = q;
             items += q->items;
         }
@@ -1490,19 +1496,22 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
 {
     if (!in || !out || w < 1 || h < 1 || (c != 3 && c != 4)) return fail(RSR_E_ARG, "bad image arguments");
     const size_t nin = size_t(w) * h * c, nout_full = nin * size_t(scale) * scale;
-    int T = 0;
-    { // state checks BEFORE anything is enqueued on behalf of this call
+    int T = 0, mwidth = 1;
+    long long mitems = 0;
+    { // state checks BEFORE anything is enqueued on behalf of this call (and the engine's settings read under its lock)
         std::lock_guard<std::mutex> lk(mu);
         if (!loaded) return fail(RSR_E_STATE, "process before load");
         if (scale != 4) return fail(RSR_E_ARG, "only scale 4 is supported (main.cpp:533-537)");
         T = tilesize;
+        mwidth = merge_width(w, h, c);
+        if (mwidth > 1) mitems = image_items(w, h, merge_target_items);
     }
     const int xtiles = (w + T - 1) / T, ytiles = (h + T - 1) / T;
     if (tile1 < 0) tile1 = xtiles * ytiles;
     if (tile0 < 0 || tile1 > xtiles * ytiles || tile0 >= tile1) return fail(RSR_E_ARG, "tile range outside the image");
     // a small whole image is merged with the images other callers hand in meanwhile (Engine::submit_merged); a leader that is
     // forming a batch gives the calls counted here a moment to finish their upload
-    const bool mergeable = tile0 == 0 && tile1 == xtiles * ytiles && merge_width(w, h, c) > 1;
+    const bool mergeable = tile0 == 0 && tile1 == xtiles * ytiles && mwidth > 1;
     struct Inbound
     {
         std::atomic<int>* n;
@@ -1574,7 +1583,8 @@ int Engine::process_host(const uint8_t* in, int w, int h, int c, uint8_t* out, i
     {
         MergeReq r;
         r.d_in = L->d_in.p; r.d_out = dbase; r.w = w; r.h = h; r.c = c; r.T = T;
-        r.items = image_items(w, h, merge_target_items);
+        r.items = mitems;
+        r.width = mwidth;
         r.ev_in = L->ev_in;
         r.ev_done = L->ev_done;
         inbound.release(); // (it is in the queue the moment submit_merged has the lock: the leader's wait ends either way)

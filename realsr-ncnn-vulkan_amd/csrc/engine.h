@@ -106,6 +106,7 @@ struct MergeReq
     void* d_out = nullptr;
     int w = 0, h = 0, c = 0, T = 0;
     long long items = 0;          // LR-level work items of the image (Engine::image_items)
+    int width = 1;                // Engine::merge_width of its geometry when the call came in
     hipEvent_t ev_in = nullptr;   // the input is complete behind this event (null: it already is)
     hipEvent_t ev_done = nullptr; // recorded on the compute stream behind the batch (null: the leader takes one from the pool -> ev_done_pool)
     bool pool_event = false;      // ev_done came from Engine::take_event: the caller gives it back
@@ -186,8 +187,8 @@ struct Engine
     std::vector<std::unique_ptr<Lane>> lanes;
 
     // merging small images across calls (see the top of this file)
-    int merge_max = kMaxMerge;       // option "merge": images per merged batch at most (1 = off)
-    int merge_target_items = 4096;   // LR-level work items a merged batch aims at (16 per CU); an image with more than a quarter of it is not merged
+    std::atomic<int> merge_max{kMaxMerge};      // option "merge": images per merged batch at most (1 = off)
+    std::atomic<int> merge_target_items{4096};  // LR-level work items a merged batch aims at (16 per CU); an image with more than a quarter of it is not merged
     std::mutex cq_mu;
     std::condition_variable cq_cv;
     std::deque<MergeReq*> cq;        // FIFO of waiting calls, under cq_mu
@@ -199,7 +200,7 @@ struct Engine
     std::atomic<long long> merged_batches{0}, merged_images{0}, merged_widest{0}; // stats
     std::atomic<int> merge_inbound{0}; // calls with a small image that are on their way to submit_merged (uploading): a leader waits a moment for them
     long long device_direct = 0; // rsr_process_device calls that ran on the caller's own stream (the engine was idle), under mu
-    bool merge_mixed = true;         // option "merge_mixed": a merged batch may hold images of different sizes (0: of one geometry only)
+    std::atomic<bool> merge_mixed{true}; // option "merge_mixed": a merged batch may hold images of different sizes (0: of one geometry only)
     DevBuf mix_tab[3];               // rotating device tables of such batches
     hipEvent_t mix_ev[3] = {nullptr, nullptr, nullptr};
     unsigned long long mix_seq = 0;

@@ -192,6 +192,33 @@ def test_large_images_and_tile_ranges_are_not_merged(paths):
         s.close()
 
 
+def test_merged_batches_under_a_small_workspace_budget(paths):
+    """max_workspace_mb far below what a merged batch wants: the cached plan of a geometry is cut into several tile batches (a narrower
+    merged batch launches a prefix of each), a batch of mixed sizes that does not fit falls back to one image at a time -- same bytes."""
+    s = R.RealSR(0)
+    try:
+        s.load(*paths)
+        s.tilesize = 64
+        imgs = [synth.make_image(900 + i, *((150, 120) if i % 3 else (100, 70))) for i in range(18)]
+        s.set_option("merge", 1)
+        lone = [s.process(im) for im in imgs]
+        s.set_option("merge", 16)
+        s.set_option("max_workspace_mb", 200)  # one slot of 84 x 84 px x 6,048 B = 43 MB: four or so tiles per batch
+        for mixed in (0, 1):
+            s.set_option("merge_mixed", mixed)
+            outs = [None] * 18
+
+            def work(t):
+                for i in range(3 * t, 3 * t + 3):
+                    outs[i] = s.process(imgs[i], push_params=False)
+            run_threads(6, work)
+            for i in range(18):
+                assert np.array_equal(outs[i], lone[i]), (mixed, i)
+        assert s.get_stat("merged_batches") > 0 and s.get_stat("workspace_mb") <= 260
+    finally:
+        s.close()
+
+
 def test_a_failing_merged_batch_reports_to_every_caller(paths):
     """A batch whose workspace cannot be had (test hook ws_fail_above_mb) fails EVERY call that was merged into it with RSR_E_NOMEM -- nobody
     hangs, nobody gets a stale image -- and the context works again once the cause is gone."""

@@ -231,3 +231,25 @@ def test_precise_baseline_frames_against_golden_samples(name):
     n, frac = oracle_pool.check_frame_golden(out, name, img, bp, T)
     print("%s, precise mode: %d of 60 tiles within +-1 of the golden oracle samples, %.2f %% of the samples differ" % (name.upper(), n, 100 * frac))
     assert n == 60 and frac < 0.035
+
+
+def test_precise_tile_ranges_and_group_equal_the_whole_image(paths):
+    """Tile ranges (rsr_process_rows / rsr_process_group: what several GPUs do with one image) in precise mode: the pieces put together
+    equal the whole-image call, RGB (fused conv_last, output rows relative to the range's first) and RGBA (planar fp32 blob)."""
+    for c in (3, 4):
+        img = synth.make_image(21, 150, 130, c)
+        a, b = R.RealSR(0), R.RealSR(0)
+        try:
+            for s in (a, b):
+                s.load(*paths)
+                s.tilesize = 48
+                s.set_option("precise", 1)
+            whole = a.process(img)
+            out = np.zeros_like(whole)
+            a.process_rows(img, out, 0, 1)
+            b.process_rows(img, out, 1, 3)
+            assert np.array_equal(out, whole), c
+            assert np.array_equal(R.process_group([a, b, a], img), whole), c
+        finally:
+            a.close()
+            b.close()

@@ -54,6 +54,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x4 __attribute__((may_alias)) f32x4_lds;
 
 namespace {
@@ -112,11 +113,14 @@ __device__ __forceinline__ char* uniform_ptr(const void* p)
     return reinterpret_cast<char*>((unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
-// four bf8 (e5m2) bytes -> fp32 (the byte selector of v_cvt_f32_bf8 is an immediate)
-__device__ __forceinline__ void bf8x4_to_f32(unsigned w, float (&o)[4])
+// two bf8 (e5m2) bytes of a dword -> fp32 / two fp32 -> two bf8 bytes of a dword (the word selector of v_cvt_pk_* is an immediate)
+__device__ __forceinline__ f32x2 bf8_pair(unsigned w, int hiword)
 {
-    o[0] = __builtin_amdgcn_cvt_f32_bf8(int(w), 0); o[1] = __builtin_amdgcn_cvt_f32_bf8(int(w), 1);
-    o[2] = __builtin_amdgcn_cvt_f32_bf8(int(w), 2); o[3] = __builtin_amdgcn_cvt_f32_bf8(int(w), 3);
+    return hiword ? __builtin_amdgcn_cvt_pk_f32_bf8(int(w), true) : __builtin_amdgcn_cvt_pk_f32_bf8(int(w), false);
+}
+__device__ __forceinline__ int pack_bf8_pair(float x, float y, int old, int hiword)
+{
+    return hiword ? __builtin_amdgcn_cvt_pk_bf8_f32(x, y, old, true) : __builtin_amdgcn_cvt_pk_bf8_f32(x, y, old, false);
 }
 
 #define RSR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
@@ -562,37 +566,36 @@ __global__ __launch_bounds__((4 * NT / NTW + 4) * 64, (4 * NT / NTW + 4) / 4) vo
 #pragma unroll
         for (int p = 0; p < 2; p++)
         {
-            // four values at a time (one dword of the lo bytes): the 168-VGPR budget has no room for a whole decoded row
+            // Four values at a time (one dword of the lo bytes: the 168-VGPR budget has no room for a whole decoded row), in PAIRS: this
+            // epilogue is bound by its VALU issue slots (8 instructions per value against 2 in EPI 2), and packed fp32 arithmetic
+            // (v_pk_mul / v_pk_fma / v_pk_add), v_cvt_pk_f32_bf8 and v_cvt_pk_bf8_f32 halve them.  Rounding points as before: the product
+            // acc * s1 is rounded to fp32 before anything is added (an explicit fma takes it as its addend: nothing can be contracted).
             half8 vh;
             const half8 r = __builtin_bit_cast(half8, r2h[p]);
 #pragma unroll
             for (int k = 0; k < 2; k++)
             {
-                float f[4], lf[4];
-                bf8x4_to_f32(l1[p * 2 + k], lf);
+                int wq = 0;
 #pragma unroll
-                for (int e = 0; e < 4; e++)
+                for (int e2 = 0; e2 < 2; e2++)
                 {
-                    float v = acc[p * 8 + k * 4 + e] * a.s1;
-                    asm volatile("" : "+v"(v)); // every variant rounds the product before anything is added (see row_emit)
-                    f[e] = __builtin_fmaf(lf[e], kLoInv, v);
+                    const int c0 = p * 8 + k * 4 + e2 * 2; // accumulator register of the pair's first value
+                    const f32x2 av = {acc[c0], acc[c0 + 1]};
+                    const f32x2 kinv = {kLoInv, kLoInv}, s1v = {a.s1, a.s1};
+                    f32x2 f = __builtin_elementwise_fma(bf8_pair(l1[p * 2 + k], e2), kinv, av * s1v);
+                    if (EPI == 5)
+                    {
+                        const f32x2 rv = {(float)r[k * 4 + e2 * 2], (float)r[k * 4 + e2 * 2 + 1]}, s2v = {a.s2, a.s2};
+                        f = __builtin_elementwise_fma(bf8_pair(r2l[p * 2 + k], e2), kinv, __builtin_elementwise_fma(f, s2v, rv));
+                    }
+                    asm volatile("" : "+v"(f)); // f is an fp32 VALUE (hi rounds it, lo keeps its residue): the compiler must not fuse the fma above into the fp16 conversion
+                    const half2v hv = __builtin_convertvector(f, half2v);
+                    vh[k * 4 + e2 * 2] = hv[0];
+                    vh[k * 4 + e2 * 2 + 1] = hv[1];
+                    const f32x2 ksc = {kLoScale, kLoScale};
+                    const f32x2 t = (f - __builtin_convertvector(hv, f32x2)) * ksc; // exact: hv is f rounded to 11 bits; <= half an ulp x 2048, never beyond 32768
+                    wq = pack_bf8_pair(t[0], t[1], wq, e2);
                 }
-                if (EPI == 5)
-                {
-                    bf8x4_to_f32(r2l[p * 2 + k], lf);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) f[e] = __builtin_fmaf(lf[e], kLoInv, __builtin_fmaf(f[e], a.s2, (float)r[k * 4 + e]));
-                }
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                {
-                    vh[k * 4 + e] = (_Float16)f[e];
-                    float t = f[e] - (float)vh[k * 4 + e]; // exact: vh is f rounded to 11 bits
-                    asm volatile("" : "+v"(t));
-                    f[e] = t * kLoScale; // <= half an ulp of vh, x 2048: never beyond 32768
-                }
-                int wq = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], 0, false);
-                wq = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], wq, true);
                 vl[p * 2 + k] = unsigned(wq);
             }
             const unsigned poff = unsigned(n * 2 + p) * pstride;
